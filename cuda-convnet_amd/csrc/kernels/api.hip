@@ -1,0 +1,330 @@
+// api.hip -- extern "C" entry points for the contraction kernels (conv / local / dense),
+// error reporting, device query, split-K reduction, and the unshared (local) layer kernels.
+#include <string.h>
+#include "mc_common.h"
+
+namespace mc {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int num_cus() {
+    static thread_local int dev_cached = -1;
+    static thread_local int cus = 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return cus;
+    if (dev != dev_cached) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        dev_cached = dev;
+    }
+    return cus;
+}
+
+// implemented in igemm.hip
+int conv_filter_acts_impl(const float*, const float*, float*, const float*, int, int, int, int, int, int, int, int, int, int,
+                          int, int, float, float, hipStream_t);
+int conv_img_acts_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int, int, float,
+                       float, hipStream_t);
+int conv_weight_acts_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int, int, int,
+                          float, float, hipStream_t);
+int gemm_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, float, float, const float*, int,
+              int, long, hipStream_t);
+
+namespace {
+
+constexpr int TPB = 256;
+
+// out[i][j] = beta*C + alpha*sum_q slab[q][i][j] (+bias[i]) (relu)
+__global__ void k_splitk_reduce(const float* __restrict__ slabs, float* C, int m, int n, int ldc, int chunks, float alpha,
+                                float beta, const float* __restrict__ bias, int act) {
+    const size_t total = (size_t)m * n;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / n), j = (int)(e - (size_t)i * n);
+        float acc = 0.f;
+        for (int q = 0; q < chunks; ++q) acc += slabs[(size_t)q * total + e];
+        float v = alpha * acc;
+        const size_t idx = (size_t)i * ldc + j;
+        if (beta != 0.f) v += beta * C[idx];
+        if (bias) v += bias[i];
+        if (act == MC_NEURON_RELU) v = v < 0.f ? 0.f : v;
+        C[idx] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Unshared (local) layers: per-module filter banks W[m][c][p][f]
+// (Kernel/src/conv/filter_acts.cu:100-102 with conv=false).  Weight-bandwidth bound and
+// tiny in flops at the BASELINE shapes; straightforward coalesced kernels, 4 images per lane.
+// ---------------------------------------------------------------------------------
+struct LG {
+    int N, C, H, W, F, fs, fp, pad, stride, MY, MX, M, fc, fpg, groups;
+};
+
+template <int V>
+__global__ void k_local_filter_acts(const float* __restrict__ images, const float* __restrict__ filters, float* targets,
+                                    LG g, float sT, float sO) {
+    const int nChunks = g.N / V;
+    const size_t total = (size_t)g.F * g.M * nChunks;
+    for (size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(item / nChunks);
+        const int n = (int)(item - (size_t)row * nChunks) * V;
+        const int f = row / g.M, m = row - f * g.M;
+        const int grp = f / g.fpg;
+        const int my = m / g.MX, mx = m - my * g.MX;
+        const int y0 = g.pad + my * g.stride, x0 = g.pad + mx * g.stride;
+        float acc[V];
+#pragma unroll
+        for (int u = 0; u < V; ++u) acc[u] = 0.f;
+        for (int c = 0; c < g.fc; ++c)
+            for (int fy = 0; fy < g.fs; ++fy) {
+                const int y = y0 + fy;
+                if (y < 0 || y >= g.H) continue;
+                for (int fx = 0; fx < g.fs; ++fx) {
+                    const int x = x0 + fx;
+                    if (x < 0 || x >= g.W) continue;
+                    const float w = filters[((size_t)(m * g.fc + c) * g.fp + fy * g.fs + fx) * g.F + f];
+                    const float* src = images + ((size_t)((grp * g.fc + c) * g.H + y) * g.W + x) * g.N + n;
+                    if (V == 4) {
+                        const float4 v = *reinterpret_cast<const float4*>(src);
+                        acc[0] += w * v.x; acc[1 % V] += w * v.y; acc[2 % V] += w * v.z; acc[3 % V] += w * v.w;
+                    } else {
+                        acc[0] += w * src[0];
+                    }
+                }
+            }
+        float* t = targets + (size_t)row * g.N + n;
+#pragma unroll
+        for (int u = 0; u < V; ++u) t[u] = (sT == 0.f ? 0.f : sT * t[u]) + sO * acc[u];
+    }
+}
+
+template <int V>
+__global__ void k_local_img_acts(const float* __restrict__ hidActs, const float* __restrict__ filters, float* targets,
+                                 LG g, float sT, float sO) {
+    const int nChunks = g.N / V;
+    const int imgPix = g.H * g.W;
+    const size_t total = (size_t)g.C * imgPix * nChunks;
+    for (size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(item / nChunks);
+        const int n = (int)(item - (size_t)row * nChunks) * V;
+        const int c = row / imgPix, px = row - c * imgPix;
+        const int y = px / g.W, x = px - y * g.W;
+        const int grp = c / g.fc, cl = c - grp * g.fc;
+        float acc[V];
+#pragma unroll
+        for (int u = 0; u < V; ++u) acc[u] = 0.f;
+        for (int my = 0; my < g.MY; ++my) {
+            const int fy = y - (g.pad + my * g.stride);
+            if (fy < 0 || fy >= g.fs) continue;
+            for (int mx = 0; mx < g.MX; ++mx) {
+                const int fx = x - (g.pad + mx * g.stride);
+                if (fx < 0 || fx >= g.fs) continue;
+                const int m = my * g.MX + mx;
+                const float* wrow = filters + ((size_t)(m * g.fc + cl) * g.fp + fy * g.fs + fx) * g.F;
+                for (int f = grp * g.fpg; f < (grp + 1) * g.fpg; ++f) {
+                    const float w = wrow[f];
+                    const float* src = hidActs + ((size_t)f * g.M + m) * g.N + n;
+                    if (V == 4) {
+                        const float4 v = *reinterpret_cast<const float4*>(src);
+                        acc[0] += w * v.x; acc[1 % V] += w * v.y; acc[2 % V] += w * v.z; acc[3 % V] += w * v.w;
+                    } else {
+                        acc[0] += w * src[0];
+                    }
+                }
+            }
+        }
+        float* t = targets + (size_t)row * g.N + n;
+#pragma unroll
+        for (int u = 0; u < V; ++u) t[u] = (sT == 0.f ? 0.f : sT * t[u]) + sO * acc[u];
+    }
+}
+
+int make_lg(LG& g, int N, int C, int H, int W, int F, int fs, int pad, int stride, int MY, int MX, int groups, const char* who) {
+    MC_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && F > 0 && fs > 0 && stride > 0 && MY > 0 && MX > 0 && groups > 0,
+               "%s: non-positive dimension", who);
+    MC_REQUIRE(pad <= 0, "%s: paddingStart must be <= 0 (got %d)", who, pad);
+    MC_REQUIRE(C % groups == 0 && F % groups == 0, "%s: channels and filters must be divisible by groups", who);
+    MC_REQUIRE((size_t)N * C * H * W < (1ull << 31) && (size_t)N * F * MY * MX < (1ull << 31), "%s: tensor exceeds 32-bit indexing", who);
+    g = LG{N, C, H, W, F, fs, fs * fs, pad, stride, MY, MX, MY * MX, C / groups, F / groups, groups};
+    return MC_OK;
+}
+
+inline int grid_items(size_t items) {
+    const size_t want = (items + TPB - 1) / TPB;
+    const size_t cap = (size_t)num_cus() * 16;
+    return (int)(want < 1 ? 1 : (want > cap ? cap : want));
+}
+
+int pick_gemm_chunks(int m, int n, int k) {
+    const long tiles = (long)ceil_div(m, 32) * ceil_div(n, 128);
+    if (k < 2048 || tiles >= num_cus()) return 1;
+    long want = (2L * num_cus() + tiles - 1) / tiles;
+    const long maxc = k / 512;
+    if (want > maxc) want = maxc;
+    if (want > 64) want = 64;
+    return want < 1 ? 1 : (int)want;
+}
+
+}  // namespace
+}  // namespace mc
+
+using namespace mc;
+
+extern "C" {
+
+const char* mc_last_error(void) { return g_err; }
+
+int mc_device_info(char* archName, int archNameLen, int* numCUs) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { set_error("mc_device_info: %s", hipGetErrorString(e)); return MC_ELAUNCH; }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) { set_error("mc_device_info: %s", hipGetErrorString(e)); return MC_ELAUNCH; }
+    if (archName && archNameLen > 0) {
+        strncpy(archName, prop.gcnArchName, archNameLen - 1);
+        archName[archNameLen - 1] = 0;
+    }
+    if (numCUs) *numCUs = prop.multiProcessorCount;
+    return MC_OK;
+}
+
+int mc_conv_filter_acts(const float* images, const float* filters, float* targets, int numImages, int numImgColors,
+                        int imgSizeY, int imgSizeX, int numFilters, int filterSize, int paddingStart, int moduleStride,
+                        int numModulesY, int numModulesX, int numGroups, float scaleTargets, float scaleOutput,
+                        mcStream_t s) {
+    MC_REQUIRE(images && filters && targets, "mc_conv_filter_acts: null pointer");
+    return conv_filter_acts_impl(images, filters, targets, nullptr, MC_NEURON_NONE, numImages, numImgColors, imgSizeY,
+                                 imgSizeX, numFilters, filterSize, paddingStart, moduleStride, numModulesY, numModulesX,
+                                 numGroups, scaleTargets, scaleOutput, S(s));
+}
+
+int mc_conv_filter_acts_fused(const float* images, const float* filters, float* targets, const float* biases, int neuron,
+                              int numImages, int numImgColors, int imgSizeY, int imgSizeX, int numFilters, int filterSize,
+                              int paddingStart, int moduleStride, int numModulesY, int numModulesX, int numGroups,
+                              float scaleTargets, float scaleOutput, mcStream_t s) {
+    MC_REQUIRE(images && filters && targets, "mc_conv_filter_acts_fused: null pointer");
+    MC_REQUIRE(neuron == MC_NEURON_NONE || neuron == MC_NEURON_RELU, "mc_conv_filter_acts_fused: unknown neuron %d", neuron);
+    return conv_filter_acts_impl(images, filters, targets, biases, neuron, numImages, numImgColors, imgSizeY, imgSizeX,
+                                 numFilters, filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups,
+                                 scaleTargets, scaleOutput, S(s));
+}
+
+int mc_conv_img_acts(const float* hidActs, const float* filters, float* targets, int numImages, int numImgColors,
+                     int imgSizeY, int imgSizeX, int numFilters, int filterSize, int paddingStart, int moduleStride,
+                     int numModulesY, int numModulesX, int numGroups, float scaleTargets, float scaleOutput, mcStream_t s) {
+    MC_REQUIRE(hidActs && filters && targets, "mc_conv_img_acts: null pointer");
+    return conv_img_acts_impl(hidActs, filters, targets, numImages, numImgColors, imgSizeY, imgSizeX, numFilters, filterSize,
+                              paddingStart, moduleStride, numModulesY, numModulesX, numGroups, scaleTargets, scaleOutput,
+                              S(s));
+}
+
+int mc_conv_weight_acts(const float* images, const float* hidActs, float* targets, int numImages, int numImgColors,
+                        int imgSizeY, int imgSizeX, int numFilters, int filterSize, int paddingStart, int moduleStride,
+                        int numModulesY, int numModulesX, int numGroups, int partialSum, float scaleTargets,
+                        float scaleOutput, mcStream_t s) {
+    MC_REQUIRE(images && hidActs && targets, "mc_conv_weight_acts: null pointer");
+    return conv_weight_acts_impl(images, hidActs, targets, numImages, numImgColors, imgSizeY, imgSizeX, numFilters,
+                                 filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups, partialSum,
+                                 scaleTargets, scaleOutput, S(s));
+}
+
+int mc_local_weight_acts(const float* images, const float* hidActs, float* targets, int numImages, int numImgColors,
+                         int imgSizeY, int imgSizeX, int numFilters, int filterSize, int paddingStart, int moduleStride,
+                         int numModulesY, int numModulesX, int numGroups, float scaleTargets, float scaleOutput,
+                         mcStream_t s) {
+    MC_REQUIRE(images && hidActs && targets, "mc_local_weight_acts: null pointer");
+    // unshared weight gradient == shared one with partialSum = 1 (weight_acts.cu:1103-1108): every
+    // module's chunk IS that module's filter bank.
+    return conv_weight_acts_impl(images, hidActs, targets, numImages, numImgColors, imgSizeY, imgSizeX, numFilters,
+                                 filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 1,
+                                 scaleTargets, scaleOutput, S(s));
+}
+
+int mc_conv_weight_acts_pick_partial_sum(int numImages, int numImgColors, int numFilters, int filterSize, int numModules,
+                                         int numGroups) {
+    if (numImages <= 0 || numImgColors <= 0 || numFilters <= 0 || filterSize <= 0 || numModules <= 0 || numGroups <= 0) return 0;
+    const long rows = (long)(numImgColors / numGroups) * filterSize * filterSize;
+    const long tiles = (long)ceil_div(rows, 96) * ceil_div(numFilters / numGroups, 256) * numGroups;
+    long want = (2L * num_cus() + tiles - 1) / tiles;
+    if (want < 1) want = 1;
+    if (want > numModules) want = numModules;
+    // keep each chunk's k extent (partialSum*numImages) >= 512 where possible
+    while (want > 1 && (long)(numModules / want) * numImages < 512) --want;
+    int best = numModules;  // partialSum candidates: divisors of numModules
+    for (int ps = 1; ps <= numModules; ++ps)
+        if (numModules % ps == 0 && numModules / ps >= want) best = ps;
+    return best;
+}
+
+int mc_local_filter_acts(const float* images, const float* filters, float* targets, int numImages, int numImgColors,
+                         int imgSizeY, int imgSizeX, int numFilters, int filterSize, int paddingStart, int moduleStride,
+                         int numModulesY, int numModulesX, int numGroups, float scaleTargets, float scaleOutput,
+                         mcStream_t s) {
+    MC_REQUIRE(images && filters && targets, "mc_local_filter_acts: null pointer");
+    LG g;
+    int rc = make_lg(g, numImages, numImgColors, imgSizeY, imgSizeX, numFilters, filterSize, paddingStart, moduleStride,
+                     numModulesY, numModulesX, numGroups, "mc_local_filter_acts");
+    if (rc) return rc;
+    const bool v = numImages % 4 == 0 && aligned16(images) && aligned16(targets);
+    const size_t items = (size_t)g.F * g.M * (g.N / (v ? 4 : 1));
+    if (v) hipLaunchKernelGGL(k_local_filter_acts<4>, dim3(grid_items(items)), dim3(TPB), 0, S(s), images, filters, targets, g, scaleTargets, scaleOutput);
+    else hipLaunchKernelGGL(k_local_filter_acts<1>, dim3(grid_items(items)), dim3(TPB), 0, S(s), images, filters, targets, g, scaleTargets, scaleOutput);
+    return launch_status("mc_local_filter_acts");
+}
+
+int mc_local_img_acts(const float* hidActs, const float* filters, float* targets, int numImages, int numImgColors,
+                      int imgSizeY, int imgSizeX, int numFilters, int filterSize, int paddingStart, int moduleStride,
+                      int numModulesY, int numModulesX, int numGroups, float scaleTargets, float scaleOutput, mcStream_t s) {
+    MC_REQUIRE(hidActs && filters && targets, "mc_local_img_acts: null pointer");
+    LG g;
+    int rc = make_lg(g, numImages, numImgColors, imgSizeY, imgSizeX, numFilters, filterSize, paddingStart, moduleStride,
+                     numModulesY, numModulesX, numGroups, "mc_local_img_acts");
+    if (rc) return rc;
+    const bool v = numImages % 4 == 0 && aligned16(hidActs) && aligned16(targets);
+    const size_t items = (size_t)g.C * g.H * g.W * (g.N / (v ? 4 : 1));
+    if (v) hipLaunchKernelGGL(k_local_img_acts<4>, dim3(grid_items(items)), dim3(TPB), 0, S(s), hidActs, filters, targets, g, scaleTargets, scaleOutput);
+    else hipLaunchKernelGGL(k_local_img_acts<1>, dim3(grid_items(items)), dim3(TPB), 0, S(s), hidActs, filters, targets, g, scaleTargets, scaleOutput);
+    return launch_status("mc_local_img_acts");
+}
+
+size_t mc_gemm_workspace_bytes(int m, int n, int k) {
+    if (m <= 0 || n <= 0 || k <= 0) return 0;
+    const int chunks = pick_gemm_chunks(m, n, k);
+    return chunks > 1 ? (size_t)chunks * m * n * sizeof(float) : 0;
+}
+
+int mc_gemm(const float* A, const float* B, float* C, int m, int n, int k, int transA, int transB, int lda, int ldb,
+            int ldc, float scaleTargets, float scaleOutput, const float* rowBias, int neuron, void* workspace,
+            size_t workspaceBytes, mcStream_t s) {
+    MC_REQUIRE(A && B && C, "mc_gemm: null pointer");
+    MC_REQUIRE(m > 0 && n > 0 && k > 0, "mc_gemm: non-positive dimension (%d,%d,%d)", m, n, k);
+    MC_REQUIRE(lda >= (transA ? m : k) && ldb >= (transB ? k : n) && ldc >= n, "mc_gemm: leading dimension too small");
+    MC_REQUIRE(neuron == MC_NEURON_NONE || neuron == MC_NEURON_RELU, "mc_gemm: unknown neuron %d", neuron);
+    MC_REQUIRE((size_t)m * lda < (1ull << 31) && (size_t)k * (size_t)(lda > ldb ? lda : ldb) < (1ull << 31) && (size_t)m * ldc < (1ull << 31),
+               "mc_gemm: operand exceeds 32-bit indexing");
+    int chunks = pick_gemm_chunks(m, n, k);
+    if (chunks > 1 && workspace && workspaceBytes >= (size_t)chunks * m * n * sizeof(float) && aligned16(workspace)) {
+        float* slabs = static_cast<float*>(workspace);
+        int rc = gemm_impl(A, B, slabs, m, n, k, transA, transB, lda, ldb, n, 0.f, 1.f, nullptr, MC_NEURON_NONE, chunks,
+                           (long)m * n, S(s));
+        if (rc) return rc;
+        // gemm_impl may round the chunk size up; recompute how many slabs were written
+        int kChunk = (ceil_div(k, chunks) + 31) / 32 * 32;
+        const int written = ceil_div(k, kChunk);
+        hipLaunchKernelGGL(k_splitk_reduce, dim3(grid_items((size_t)m * n)), dim3(TPB), 0, S(s), slabs, C, m, n, ldc,
+                           written, scaleOutput, scaleTargets, rowBias, neuron);
+        return launch_status("mc_gemm(split-k reduce)");
+    }
+    return gemm_impl(A, B, C, m, n, k, transA, transB, lda, ldb, ldc, scaleTargets, scaleOutput, rowBias, neuron, 1, 0,
+                     S(s));
+}
+
+}  // extern "C"

@@ -1,0 +1,533 @@
+// igemm.hip -- fp32-MFMA implicit-GEMM engine for gfx950 (MI355X).
+//
+// One kernel template computes C(i,j) = sum_k A(i,k) * B(k,j) with both operands supplied
+// by "loaders" that know how to gather a (BK x ROWS) tile from the reference's
+// batch-innermost tensors.  The contractions of the conv-net step are all instances:
+//
+//   conv forward   (Kernel/src/conv/filter_acts.cu:58-413)  A = filters  [k][f]      B = im2col patches [k][(m,n)]
+//   conv bwd-data  (Kernel/src/conv/img_acts.cu:63-658)     A = filters^T [c][(p,f)]  B = hidActs gather [(p,f)][(px,n)]
+//   conv bwd-wts   (Kernel/src/conv/weight_acts.cu:58-409)  A = patches  [(c,p)][(m,n)]  B = hidActs [f][(m,n)]
+//   dense          (Kernel/src/nvmatrix/nvmatrix.cu:189-239) plain matrices, 4 transpose combos
+//
+// Design notes (MI355X-first, not a translation of the reference's register tiling):
+//   * wave64, v_mfma_f32_32x32x2_f32: each wave owns an (MT x NT) grid of 32x32 accumulators.
+//     A/B fragments are ONE f32 VGPR per lane: lane l supplies A[i = l&31][k = l>>5].
+//   * Two LDS layouts, chosen by which axis is contiguous in HBM:
+//       NAT  [BK][ROWS]       operand is contiguous along its row (i or j) axis -> ds_read_b32,
+//                              32 consecutive floats per half-wave: conflict free.
+//       KC   [BK/4][ROWS+1][4] operand is contiguous along k -> one ds_read_b128 feeds 4 MFMAs.
+//     Any k permutation is legal as long as A and B agree, so inside each group of 8 k's
+//     MFMA e (0..3) of lane-half h consumes k = 4h + e; that makes both layouts line up.
+//   * global -> registers -> LDS double buffering, one barrier per K step; the next tile's
+//     global loads are issued before the MFMAs of the current one.
+//   * blockIdx.z = (k-chunk q, group g): k-chunks give deterministic split-K (each chunk writes
+//     its own slab; the reference's partialSum layout is exactly that), groups are independent
+//     GEMMs on disjoint channel/filter ranges.
+#include "mc_common.h"
+
+namespace mc {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int THREADS = 256;
+
+struct ConvG {
+    int N, H, W;      // numImages, imgSizeY, imgSizeX
+    int fc;           // filter channels (per group)
+    int fs, fp;       // filterSize, filterSize^2
+    int pad, stride;  // paddingStart (<= 0), moduleStride
+    int MY, MX, M;    // modules
+    int F, fpg;       // numFilters, filters per group
+    int local;        // unshared filters (leading module index)
+    float inv_fp, inv_fs, inv_fpg, inv_N, inv_MX, inv_W;
+};
+
+struct Dims {
+    int Mg, Ng, Kg;   // GEMM extents (per group)
+    int kChunk;       // k extent of one chunk (multiple of 4 when a KC loader is vectorised)
+    int groups;
+};
+
+struct Epi {
+    float* C;
+    int ldc;
+    int rowG, colG;   // per-group row / column offset
+    long chunkStride; // per k-chunk offset (slabs)
+    float alpha, beta;
+    const float* bias;  // per output row (after group offset), nullable
+    int act;            // MC_NEURON_*
+};
+
+// exact floor(a / d) for 0 <= a < 2^22 using a precomputed float reciprocal
+__device__ __forceinline__ int fdiv(int a, float inv) { return (int)(((float)a + 0.5f) * inv); }
+
+// ---------------------------------------------------------------------------------
+// Element address functions.  Each returns the element offset of operand element
+// (k, x) and whether it is a real element (false -> contributes 0).
+// ---------------------------------------------------------------------------------
+struct MatP {
+    const float* p;
+    int ld;      // row stride of the stored matrix
+    int R;       // extent of the non-k axis (per group)
+    int gStride; // offset added per group
+};
+
+// stored (K, R): element (k, x) at k*ld + x
+struct MatNatAddr {
+    typedef MatP P;
+    static constexpr bool KC = false;
+    __device__ static __forceinline__ bool addr(const P& p, const ConvG&, int g, int k, int x, int& off) {
+        off = g * p.gStride + k * p.ld + x;
+        return x < p.R;
+    }
+    __device__ static __forceinline__ const float* base(const P& p) { return p.p; }
+};
+// stored (R, K): element (k, x) at x*ld + k
+struct MatKcAddr {
+    typedef MatP P;
+    static constexpr bool KC = true;
+    __device__ static __forceinline__ bool addr(const P& p, const ConvG&, int g, int k, int x, int& off) {
+        off = g * p.gStride + x * p.ld + k;
+        return x < p.R;
+    }
+    __device__ static __forceinline__ const float* base(const P& p) { return p.p; }
+};
+
+struct ConvP {
+    const float* p;
+    int R;  // extent of the non-k axis
+};
+
+// im2col patch element: filter tap kc = (c, fy, fx), column (m, n)
+__device__ __forceinline__ bool patch_addr(const ConvG& cg, int g, int kc, int m, int n, int& off) {
+    const int c = fdiv(kc, cg.inv_fp);
+    const int p = kc - c * cg.fp;
+    const int fy = fdiv(p, cg.inv_fs);
+    const int fx = p - fy * cg.fs;
+    const int my = fdiv(m, cg.inv_MX);
+    const int mx = m - my * cg.MX;
+    const int y = cg.pad + my * cg.stride + fy;
+    const int x = cg.pad + mx * cg.stride + fx;
+    off = (((g * cg.fc + c) * cg.H + y) * cg.W + x) * cg.N + n;
+    return (unsigned)y < (unsigned)cg.H && (unsigned)x < (unsigned)cg.W;
+}
+
+// forward B operand: k = filter tap, x = column (m*N + n); NAT (n contiguous)
+struct PatchNatAddr {
+    typedef ConvP P;
+    static constexpr bool KC = false;
+    __device__ static __forceinline__ bool addr(const P& p, const ConvG& cg, int g, int k, int x, int& off) {
+        const int m = x / cg.N;  // column decode is loop invariant in the K loop: exact integer division
+        const int n = x - m * cg.N;
+        return patch_addr(cg, g, k, m, n, off) & (x < p.R);
+    }
+    __device__ static __forceinline__ const float* base(const P& p) { return p.p; }
+};
+// weight-gradient A operand: x = filter tap (row), k = (m*N + n); KC (n contiguous)
+struct PatchKcAddr {
+    typedef ConvP P;
+    static constexpr bool KC = true;
+    __device__ static __forceinline__ bool addr(const P& p, const ConvG& cg, int g, int k, int x, int& off) {
+        const int m = fdiv(k, cg.inv_N);
+        const int n = k - m * cg.N;
+        const int xx = x < p.R ? x : 0;
+        return patch_addr(cg, g, xx, m, n, off) & (x < p.R);
+    }
+    __device__ static __forceinline__ const float* base(const P& p) { return p.p; }
+};
+// bwd-data B operand: k = (p, fl) (filter pixel, filter within group), x = (pixel*N + n); NAT
+struct HidNatAddr {
+    typedef ConvP P;
+    static constexpr bool KC = false;
+    __device__ static __forceinline__ bool addr(const P& p, const ConvG& cg, int g, int k, int x, int& off) {
+        const int px = x / cg.N;  // loop invariant in the K loop
+        const int n = x - px * cg.N;
+        const int y = px / cg.W;
+        const int xx = px - y * cg.W;
+        const int fpix = fdiv(k, cg.inv_fpg);
+        const int fl = k - fpix * cg.fpg;
+        const int fy = fdiv(fpix, cg.inv_fs);
+        const int fx = fpix - fy * cg.fs;
+        int ty = y - cg.pad - fy, tx = xx - cg.pad - fx;
+        bool ok = (ty >= 0) & (tx >= 0) & (x < p.R);
+        if (cg.stride != 1) {
+            const int my = ty / cg.stride, mx = tx / cg.stride;
+            ok &= (my * cg.stride == ty) & (mx * cg.stride == tx);
+            ty = my;
+            tx = mx;
+        }
+        ok &= (ty < cg.MY) & (tx < cg.MX);
+        off = ((g * cg.fpg + fl) * cg.M + ty * cg.MX + tx) * cg.N + n;
+        return ok;
+    }
+    __device__ static __forceinline__ const float* base(const P& p) { return p.p; }
+};
+// bwd-data A operand: x = channel within group (row), k = (p, fl); filters[(x*fp + p)*F + g*fpg + fl]; KC
+struct FiltTAddr {
+    typedef ConvP P;
+    static constexpr bool KC = true;
+    __device__ static __forceinline__ bool addr(const P& p, const ConvG& cg, int g, int k, int x, int& off) {
+        const int fpix = fdiv(k, cg.inv_fpg);
+        const int fl = k - fpix * cg.fpg;
+        off = (x * cg.fp + fpix) * cg.F + g * cg.fpg + fl;
+        return x < p.R;
+    }
+    __device__ static __forceinline__ const float* base(const P& p) { return p.p; }
+};
+
+// ---------------------------------------------------------------------------------
+// Tile loader: global -> registers (fetch) -> LDS (commit).
+//   ADDR::KC == false: LDS [BK][ROWS] floats, chunk = 4 consecutive x at one k
+//   ADDR::KC == true : LDS [BK/4][ROWS+1] float4, chunk = 4 consecutive k at one x
+// VEC == 4: one predicated 16-byte load per chunk (caller guarantees alignment and that
+// a chunk never straddles a validity boundary); VEC == 1: four predicated scalar loads.
+// ---------------------------------------------------------------------------------
+template <class ADDR, int ROWS, int BK, int VEC>
+struct Loader {
+    typedef typename ADDR::P P;
+    static constexpr bool KC = ADDR::KC;
+    static constexpr int ROWSP = ROWS + 1;
+    static constexpr int LDS_FLOATS = KC ? (BK / 4) * ROWSP * 4 : BK * ROWS;
+    static constexpr int CHUNKS = BK * ROWS / 4;
+    static constexpr int NCH = (CHUNKS + THREADS - 1) / THREADS;
+    float4 r[NCH];
+
+    // chunk c -> (k offset inside tile, x offset inside tile) of its first element
+    __device__ static __forceinline__ void chunk_pos(int c, int& dk, int& dx) {
+        if (KC) {
+            dk = (c % (BK / 4)) * 4;
+            dx = c / (BK / 4);
+        } else {
+            dk = c / (ROWS / 4);
+            dx = (c % (ROWS / 4)) * 4;
+        }
+    }
+
+    __device__ __forceinline__ void fetch(const P& p, const ConvG& cg, int g, int k0, int kend, int x0, int tid) {
+        const float* base = ADDR::base(p);
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) {
+            const int c = tid + it * THREADS;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (CHUNKS % THREADS == 0 || c < CHUNKS) {
+                int dk, dx;
+                chunk_pos(c, dk, dx);
+                const int k = k0 + dk, x = x0 + dx;
+                if (VEC == 4) {
+                    int off;
+                    const bool ok = ADDR::addr(p, cg, g, k, x, off) & (k < kend);
+                    if (ok) v = *reinterpret_cast<const float4*>(base + off);
+                } else {
+                    float e[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ku = KC ? k + u : k, xu = KC ? x : x + u;
+                        int off;
+                        const bool ok = ADDR::addr(p, cg, g, ku, xu, off) & (ku < kend);
+                        e[u] = ok ? base[off] : 0.f;
+                    }
+                    v = make_float4(e[0], e[1], e[2], e[3]);
+                }
+            }
+            r[it] = v;
+        }
+    }
+
+    __device__ __forceinline__ void commit(float* lds, int tid) const {
+        float4* l4 = reinterpret_cast<float4*>(lds);
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) {
+            const int c = tid + it * THREADS;
+            if (CHUNKS % THREADS == 0 || c < CHUNKS) {
+                if (KC) {
+                    l4[(c % (BK / 4)) * ROWSP + c / (BK / 4)] = r[it];
+                } else {
+                    l4[c] = r[it];  // [dk][dx/4] == linear chunk order
+                }
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------
+// The kernel.  256 threads = 4 waves laid out WM x WN; wave tile (32*MT) x (32*NT).
+// ---------------------------------------------------------------------------------
+template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC>
+__global__ void __launch_bounds__(THREADS)
+mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+    typedef Loader<AADDR, BM, BK, VEC> LA;
+    typedef Loader<BADDR, BN, BK, VEC> LB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA0 = smem;
+    float* sA1 = smem + LA::LDS_FLOATS;
+    float* sB0 = smem + 2 * LA::LDS_FLOATS;
+    float* sB1 = sB0 + LB::LDS_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+    const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+    const int q = blockIdx.z / d.groups, g = blockIdx.z - q * d.groups;
+    const int kbeg = q * d.kChunk;
+    const int kend = min(kbeg + d.kChunk, d.Kg);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    LA la;
+    LB lb;
+    la.fetch(pa, cg, g, kbeg, kend, i0, tid);
+    lb.fetch(pb, cg, g, kbeg, kend, j0, tid);
+    la.commit(sA0, tid);
+    lb.commit(sB0, tid);
+    __syncthreads();
+
+    for (int t = 0; t < nk; ++t) {
+        const float* cA = (t & 1) ? sA1 : sA0;
+        const float* cB = (t & 1) ? sB1 : sB0;
+        const bool more = t + 1 < nk;
+        if (more) {
+            la.fetch(pa, cg, g, kbeg + (t + 1) * BK, kend, i0, tid);
+            lb.fetch(pb, cg, g, kbeg + (t + 1) * BK, kend, j0, tid);
+        }
+#pragma unroll
+        for (int k8 = 0; k8 < BK / 8; ++k8) {
+            float af[MT][4], bf[NT][4];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const int row = (wm * MT + a) * 32 + l31;
+                if (LA::KC) {
+                    const float4 v = reinterpret_cast<const float4*>(cA)[(k8 * 2 + h) * LA::ROWSP + row];
+                    af[a][0] = v.x; af[a][1] = v.y; af[a][2] = v.z; af[a][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) af[a][e] = cA[(k8 * 8 + 4 * h + e) * BM + row];
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int col = (wn * NT + b) * 32 + l31;
+                if (LB::KC) {
+                    const float4 v = reinterpret_cast<const float4*>(cB)[(k8 * 2 + h) * LB::ROWSP + col];
+                    bf[b][0] = v.x; bf[b][1] = v.y; bf[b][2] = v.z; bf[b][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bf[b][e] = cB[(k8 * 8 + 4 * h + e) * BN + col];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][e], bf[b][e], acc[a][b], 0, 0, 0);
+        }
+        if (more) {
+            la.commit((t & 1) ? sA0 : sA1, tid);
+            lb.commit((t & 1) ? sB0 : sB1, tid);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* C = ep.C + q * ep.chunkStride;
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int j = j0 + (wn * NT + b) * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + (wm * MT + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (i < d.Mg && j < d.Ng) {
+                    const int row = i + g * ep.rowG;
+                    const long idx = (long)row * ep.ldc + j + g * ep.colG;
+                    float v = ep.alpha * acc[a][b][r];
+                    if (ep.beta != 0.f) v += ep.beta * C[idx];
+                    if (ep.bias) v += ep.bias[row];
+                    if (ep.act == MC_NEURON_RELU) v = v < 0.f ? 0.f : v;
+                    C[idx] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Host-side launch helpers
+// ---------------------------------------------------------------------------------
+template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC>
+int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const ConvG& cg, const Dims& d,
+               const Epi& ep, int chunks, hipStream_t st) {
+    constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+    typedef Loader<AADDR, BM, BK, VEC> LA;
+    typedef Loader<BADDR, BN, BK, VEC> LB;
+    constexpr size_t lds = 2 * (LA::LDS_FLOATS + LB::LDS_FLOATS) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = mc_igemm<AADDR, BADDR, MT, NT, WM, WN, BK, VEC>;
+    static bool attr_done = false;
+    if (lds > 48 * 1024 && !attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 grid(ceil_div(d.Ng, BN), ceil_div(d.Mg, BM), chunks * d.groups);
+    if (grid.y > 65535 || grid.z > 65535) {
+        set_error("igemm: grid too large (%u,%u,%u)", grid.x, grid.y, grid.z);
+        return MC_EINVAL;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(THREADS), lds, st, pa, pb, cg, d, ep);
+    return launch_status("mc_igemm");
+}
+
+// Tile choice.  The MFMA pipe is the bound (64 cycles per 32x32x2 per SIMD), so what matters is
+// (a) not padding the row dimension much, (b) enough workgroups to cover 256 CUs.
+template <class AADDR, class BADDR, int BK, int VEC>
+int launch_rows_cols(const typename AADDR::P& pa, const typename BADDR::P& pb, const ConvG& cg, const Dims& d,
+                     const Epi& ep, int chunks, hipStream_t st) {
+    const int Mg = d.Mg;
+    const long colTiles128 = ceil_div(d.Ng, 128);
+    const long z = (long)chunks * d.groups;
+    // candidate row tiles (BM) with 4 waves along columns: 32, 64, 96, 128(2x2 waves)
+    const int mt32 = ceil_div(Mg, 32);
+    // waste-free preference: largest of {3,2,1} x 32 dividing the padded row count
+    int MTsel = 1;
+    if (mt32 % 3 == 0) MTsel = 3; else if (mt32 % 2 == 0) MTsel = 2;
+    // if the grid would be too small, use the 32-row tile
+    const long blocks_big = (long)ceil_div(Mg, 32 * MTsel) * ceil_div(d.Ng, 256) * z;
+    if (blocks_big < 2L * num_cus()) {
+        const long blocks_mid = (long)ceil_div(Mg, 32 * MTsel) * colTiles128 * z;
+        if (blocks_mid < 2L * num_cus() || MTsel == 1)
+            return launch_cfg<AADDR, BADDR, 1, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+        if (MTsel == 3) return launch_cfg<AADDR, BADDR, 3, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+        return launch_cfg<AADDR, BADDR, 2, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+    }
+    if (MTsel == 3) return launch_cfg<AADDR, BADDR, 3, 2, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+    if (MTsel == 2) return launch_cfg<AADDR, BADDR, 2, 2, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+    return launch_cfg<AADDR, BADDR, 1, 2, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+}
+
+inline float finv(int d) { return 1.0f / (float)d; }
+
+int make_convg(ConvG& cg, int N, int C, int H, int W, int F, int fs, int pad, int stride, int MY, int MX, int groups,
+               int local, const char* who) {
+    MC_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && F > 0 && fs > 0 && stride > 0 && MY > 0 && MX > 0 && groups > 0,
+               "%s: non-positive dimension", who);
+    MC_REQUIRE(pad <= 0, "%s: paddingStart must be <= 0 (got %d)", who, pad);
+    MC_REQUIRE(C % groups == 0 && F % groups == 0, "%s: channels (%d) and filters (%d) must be divisible by groups (%d)",
+               who, C, F, groups);
+    const long biggest = (long)N * (long)((long)C * H * W > (long)F * MY * MX ? (long)C * H * W : (long)F * MY * MX);
+    MC_REQUIRE(biggest < (1L << 31), "%s: tensor with %ld elements exceeds 32-bit indexing", who, biggest);
+    // fdiv() decodes the K index with a float reciprocal, exact below 2^22
+    MC_REQUIRE((long)MY * MX * N < (1L << 22) && (long)(C / groups) * fs * fs < (1L << 22) && (long)fs * fs * (F / groups) < (1L << 22),
+               "%s: modules*images, channels*taps and taps*filters must each be < 2^22", who);
+    cg.N = N; cg.H = H; cg.W = W; cg.fc = C / groups; cg.fs = fs; cg.fp = fs * fs; cg.pad = pad; cg.stride = stride;
+    cg.MY = MY; cg.MX = MX; cg.M = MY * MX; cg.F = F; cg.fpg = F / groups; cg.local = local;
+    cg.inv_fp = finv(cg.fp); cg.inv_fs = finv(fs); cg.inv_fpg = finv(cg.fpg); cg.inv_N = finv(N); cg.inv_MX = finv(MX);
+    cg.inv_W = finv(W);
+    return MC_OK;
+}
+
+}  // namespace
+
+// =================================================================================
+// conv forward: C[f][(m,n)] ; Mg = F/groups, Ng = M*N, Kg = fc*fp
+// =================================================================================
+int conv_filter_acts_impl(const float* images, const float* filters, float* targets, const float* biases, int neuron,
+                          int N, int C, int H, int W, int F, int fs, int pad, int stride, int MY, int MX, int groups,
+                          float scaleTargets, float scaleOutput, hipStream_t st) {
+    ConvG cg;
+    int rc = make_convg(cg, N, C, H, W, F, fs, pad, stride, MY, MX, groups, 0, "convFilterActs");
+    if (rc) return rc;
+    Dims d{cg.fpg, cg.M * N, cg.fc * cg.fp, cg.fc * cg.fp, groups};
+    Epi ep{targets, cg.M * N, cg.fpg, 0, 0, scaleOutput, scaleTargets, biases, neuron};
+    MatP pa{filters, F, cg.fpg, cg.fpg};  // filters[k*F + g*fpg + f]
+    ConvP pb{images, cg.M * N};
+    const bool vec = (N % 4 == 0) && (cg.fpg % 4 == 0) && (F % 4 == 0) && aligned16(images) && aligned16(filters);
+    if (vec) return launch_rows_cols<MatNatAddr, PatchNatAddr, 16, 4>(pa, pb, cg, d, ep, 1, st);
+    return launch_rows_cols<MatNatAddr, PatchNatAddr, 16, 1>(pa, pb, cg, d, ep, 1, st);
+}
+
+// =================================================================================
+// conv bwd-data: C[c][(px,n)] ; Mg = fc, Ng = H*W*N, Kg = fp*fpg
+// =================================================================================
+int conv_img_acts_impl(const float* hidActs, const float* filters, float* targets, int N, int C, int H, int W, int F,
+                       int fs, int pad, int stride, int MY, int MX, int groups, float scaleTargets, float scaleOutput,
+                       hipStream_t st) {
+    ConvG cg;
+    int rc = make_convg(cg, N, C, H, W, F, fs, pad, stride, MY, MX, groups, 0, "convImgActs");
+    if (rc) return rc;
+    Dims d{cg.fc, H * W * N, cg.fp * cg.fpg, cg.fp * cg.fpg, groups};
+    Epi ep{targets, H * W * N, cg.fc, 0, 0, scaleOutput, scaleTargets, nullptr, MC_NEURON_NONE};
+    ConvP pa{filters + 0, cg.fc};
+    ConvP pb{hidActs, H * W * N};
+    // group offset of the A operand rows: channel c of group g uses filter rows (cl*fp+p), columns g*fpg+fl
+    const bool vec = (N % 4 == 0) && (cg.fpg % 4 == 0) && (F % 4 == 0) && aligned16(hidActs) && aligned16(filters);
+    if (vec) return launch_rows_cols<FiltTAddr, HidNatAddr, 16, 4>(pa, pb, cg, d, ep, 1, st);
+    return launch_rows_cols<FiltTAddr, HidNatAddr, 16, 1>(pa, pb, cg, d, ep, 1, st);
+}
+
+// =================================================================================
+// conv bwd-weights: C[q][(c,p)][f] ; Mg = fc*fp, Ng = fpg, Kg = M*N, chunk = partialSum*N
+// =================================================================================
+int conv_weight_acts_impl(const float* images, const float* hidActs, float* targets, int N, int C, int H, int W, int F,
+                          int fs, int pad, int stride, int MY, int MX, int groups, int partialSum, float scaleTargets,
+                          float scaleOutput, hipStream_t st) {
+    ConvG cg;
+    int rc = make_convg(cg, N, C, H, W, F, fs, pad, stride, MY, MX, groups, 0, "convWeightActs");
+    if (rc) return rc;
+    if (partialSum <= 0) partialSum = cg.M;
+    MC_REQUIRE(cg.M % partialSum == 0, "convWeightActs: partialSum (%d) must divide numModules (%d)", partialSum, cg.M);
+    const int chunks = cg.M / partialSum;
+    Dims d{cg.fc * cg.fp, cg.fpg, cg.M * N, partialSum * N, groups};
+    Epi ep{targets, F, 0, cg.fpg, (long)cg.fc * cg.fp * F, scaleOutput, scaleTargets, nullptr, MC_NEURON_NONE};
+    ConvP pa{images, cg.fc * cg.fp};
+    MatP pb{hidActs, cg.M * N, cg.fpg, cg.fpg * cg.M * N};  // hid[(g*fpg+f)*M*N + k]
+    const bool vec = (N % 4 == 0) && aligned16(images) && aligned16(hidActs);
+    if (vec) return launch_rows_cols<PatchKcAddr, MatKcAddr, 32, 4>(pa, pb, cg, d, ep, chunks, st);
+    return launch_rows_cols<PatchKcAddr, MatKcAddr, 32, 1>(pa, pb, cg, d, ep, chunks, st);
+}
+
+// =================================================================================
+// dense: C(m,n) = beta*C + alpha*op(A)*op(B)
+// =================================================================================
+int gemm_impl(const float* A, const float* B, float* Cm, int m, int n, int k, int transA, int transB, int lda, int ldb,
+              int ldc, float beta, float alpha, const float* rowBias, int neuron, int chunks, long chunkStride,
+              hipStream_t st) {
+    ConvG cg{};
+    int kChunk = k;
+    if (chunks > 1) {
+        kChunk = ceil_div(k, chunks);
+        kChunk = (kChunk + 31) / 32 * 32;
+        chunks = ceil_div(k, kChunk);
+    }
+    Dims d{m, n, k, kChunk, 1};
+    Epi ep{Cm, ldc, 0, 0, chunkStride, alpha, beta, rowBias, neuron};
+    MatP pa{A, lda, m, 0};
+    MatP pb{B, ldb, n, 0};
+    const bool al = aligned16(A) && aligned16(B) && lda % 4 == 0 && ldb % 4 == 0;
+    // vector loads need the contiguous extent of each operand to be a multiple of 4
+    const bool va = transA ? (m % 4 == 0) : (k % 4 == 0);
+    const bool vb = transB ? (k % 4 == 0) : (n % 4 == 0);
+    const bool vec = al && va && vb;
+#define MC_GEMM_CASE(AA, BB)                                                              \
+    (vec ? launch_rows_cols<AA, BB, 16, 4>(pa, pb, cg, d, ep, chunks, st)                 \
+         : launch_rows_cols<AA, BB, 16, 1>(pa, pb, cg, d, ep, chunks, st))
+    if (transA && !transB) return MC_GEMM_CASE(MatNatAddr, MatNatAddr);
+    if (!transA && !transB) return MC_GEMM_CASE(MatKcAddr, MatNatAddr);
+    if (!transA && transB) return MC_GEMM_CASE(MatKcAddr, MatKcAddr);
+    return MC_GEMM_CASE(MatNatAddr, MatKcAddr);
+#undef MC_GEMM_CASE
+}
+
+}  // namespace mc

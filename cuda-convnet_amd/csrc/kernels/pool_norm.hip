@@ -1,0 +1,408 @@
+// pool_norm.hip -- pooling, pooling-undo and response-normalisation kernels for gfx950.
+// HBM-bound: one lane owns 4 consecutive images (16 B) of one (channel, pixel) and walks the
+// window; window re-reads are served by L1/L2, each tensor crosses HBM once.
+// Semantics follow Kernel/include/conv/conv_util.cuh:71-194 and Kernel/src/conv/conv_util.cu
+// (kLocalMaxUndo :1502, kLocalAvgUndo :1395, kCNorm_manyfilter :831, kRNormUndoPrelims :1603,
+// kRNormUndo :1639, kFCNorm :1041, kFRNormUndo :1115).
+#include "mc_common.h"
+
+namespace mc {
+namespace {
+
+constexpr int TPB = 256;
+
+// V = 4: float4 per lane (numImages % 4 == 0, aligned); V = 1: scalar fallback.
+template <int V> struct Vec;
+template <> struct Vec<4> {
+    typedef float4 T;
+    __device__ static T ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    __device__ static void st(float* p, T v) { *reinterpret_cast<float4*>(p) = v; }
+    __device__ static T splat(float s) { return make_float4(s, s, s, s); }
+};
+template <> struct Vec<1> {
+    typedef float T;
+    __device__ static T ld(const float* p) { return *p; }
+    __device__ static void st(float* p, T v) { *p = v; }
+    __device__ static T splat(float s) { return s; }
+};
+#define MC_EACH4(EXPR_X, EXPR_Y, EXPR_Z, EXPR_W) EXPR_X; EXPR_Y; EXPR_Z; EXPR_W
+__device__ __forceinline__ float4 vmax(float4 a, float4 b) { return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)); }
+__device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ float4 vadd(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float vadd(float a, float b) { return a + b; }
+__device__ __forceinline__ float4 vmul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float vmul(float a, float b) { return a * b; }
+__device__ __forceinline__ float4 vscale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float vscale(float a, float s) { return a * s; }
+__device__ __forceinline__ float4 vdivs(float4 a, float s) { return make_float4(a.x / s, a.y / s, a.z / s, a.w / s); }
+__device__ __forceinline__ float vdivs(float a, float s) { return a / s; }
+__device__ __forceinline__ float4 vdiv(float4 a, float4 b) { return make_float4(a.x / b.x, a.y / b.y, a.z / b.z, a.w / b.w); }
+__device__ __forceinline__ float vdiv(float a, float b) { return a / b; }
+// (img == act) * grad, the reference's equality routing (conv_util.cu:1567)
+__device__ __forceinline__ float4 veqmul(float4 i, float4 a, float4 g) {
+    return make_float4((i.x == a.x) * g.x, (i.y == a.y) * g.y, (i.z == a.z) * g.z, (i.w == a.w) * g.w);
+}
+__device__ __forceinline__ float veqmul(float i, float a, float g) { return (i == a) * g; }
+__device__ __forceinline__ float4 vfma_s(float s, float4 a, float4 c) { return make_float4(s * a.x + c.x, s * a.y + c.y, s * a.z + c.z, s * a.w + c.w); }
+__device__ __forceinline__ float vfma_s(float s, float a, float c) { return s * a + c; }
+__device__ __forceinline__ float4 vpow(float4 a, float e) { return make_float4(powf(a.x, e), powf(a.y, e), powf(a.z, e), powf(a.w, e)); }
+__device__ __forceinline__ float vpow(float a, float e) { return powf(a, e); }
+
+template <class T>
+__device__ __forceinline__ T blend(T old, T v, float sT, float sO) { return vadd(vscale(old, sT), vscale(v, sO)); }
+
+// item -> (row = channel*pixels + px, image chunk)
+template <int V>
+__device__ __forceinline__ bool decode(size_t item, int nChunks, int& row, int& n) {
+    row = (int)(item / nChunks);
+    n = (int)(item - (size_t)row * nChunks) * V;
+    return true;
+}
+
+// ------------------------------------------------------------------ pooling forward
+template <int V, bool MAX>
+__global__ void k_pool(const float* __restrict__ imgs, float* target, int N, int C, int imgSize, int subsX, int startX,
+                       int strideX, int outputsX) {
+    typedef Vec<V> VV;
+    const int nChunks = N / V;
+    const int numOut = outputsX * outputsX;
+    const size_t total = (size_t)C * numOut * nChunks;
+    for (size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (size_t)gridDim.x * blockDim.x) {
+        int row, n;
+        decode<V>(item, nChunks, row, n);
+        const int c = row / numOut, o = row - c * numOut;
+        const int oy = o / outputsX, ox = o - oy * outputsX;
+        const int sy = startX + oy * strideX, sx = startX + ox * strideX;
+        const int y0 = max(0, sy), x0 = max(0, sx);
+        const int y1 = min(imgSize, sy + subsX), x1 = min(imgSize, sx + subsX);
+        typename VV::T acc = VV::splat(MAX ? -2e38f : 0.f);  // conv_util.cuh:78,89-91
+        const float* src = imgs + (size_t)c * imgSize * imgSize * N + n;
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) {
+                const typename VV::T v = VV::ld(src + (size_t)(y * imgSize + x) * N);
+                acc = MAX ? vmax(acc, v) : vadd(acc, v);
+            }
+        if (!MAX) acc = vdivs(acc, (float)((y1 - y0) * (x1 - x0)));  // clipped region size, conv_util.cuh:169,190
+        VV::st(target + (size_t)row * N + n, acc);
+    }
+}
+
+__device__ __forceinline__ void out_range(int p, int start, int subs, int stride, int outputsX, int& lo, int& hi) {
+    lo = (p - start < subs) ? 0 : 1 + (p - start - subs) / stride;   // conv_util.cu:1517-1520
+    hi = min(outputsX, 1 + (p - start) / stride);
+}
+
+// ------------------------------------------------------------------ max-pool undo
+template <int V>
+__global__ void k_max_undo(const float* __restrict__ imgs, const float* __restrict__ maxGrads,
+                           const float* __restrict__ maxActs, float* target, int N, int C, int imgSize, int subsX,
+                           int startX, int strideX, int outputsX, float sT, float sO) {
+    typedef Vec<V> VV;
+    const int nChunks = N / V;
+    const int imgPix = imgSize * imgSize, numOut = outputsX * outputsX;
+    const int lim = startX + strideX * (outputsX - 1) + subsX;
+    const size_t total = (size_t)C * imgPix * nChunks;
+    for (size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (size_t)gridDim.x * blockDim.x) {
+        int row, n;
+        decode<V>(item, nChunks, row, n);
+        const int c = row / imgPix, px = row - c * imgPix;
+        const int y = px / imgSize, x = px - y * imgSize;
+        typename VV::T prod = VV::splat(0.f);
+        if (x >= startX && x < lim && y >= startX && y < lim) {  // conv_util.cu:1540-1541
+            int ylo, yhi, xlo, xhi;
+            out_range(y, startX, subsX, strideX, outputsX, ylo, yhi);
+            out_range(x, startX, subsX, strideX, outputsX, xlo, xhi);
+            const typename VV::T img = VV::ld(imgs + (size_t)row * N + n);
+            for (int my = ylo; my < yhi; ++my)
+                for (int mx = xlo; mx < xhi; ++mx) {
+                    const size_t o = ((size_t)c * numOut + my * outputsX + mx) * N + n;
+                    prod = vadd(prod, veqmul(img, VV::ld(maxActs + o), VV::ld(maxGrads + o)));
+                }
+        }
+        float* t = target + (size_t)row * N + n;
+        VV::st(t, sT == 0.f ? vscale(prod, sO) : blend(VV::ld(t), prod, sT, sO));
+    }
+}
+
+// ------------------------------------------------------------------ avg-pool undo
+template <int V>
+__global__ void k_avg_undo(const float* __restrict__ avgGrads, float* target, int N, int C, int imgSize, int subsX,
+                           int startX, int strideX, int outputsX, float sT, float sO) {
+    typedef Vec<V> VV;
+    const int nChunks = N / V;
+    const int imgPix = imgSize * imgSize, numOut = outputsX * outputsX;
+    const int lim = startX + strideX * (outputsX - 1) + subsX;
+    const size_t total = (size_t)C * imgPix * nChunks;
+    for (size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (size_t)gridDim.x * blockDim.x) {
+        int row, n;
+        decode<V>(item, nChunks, row, n);
+        const int c = row / imgPix, px = row - c * imgPix;
+        const int y = px / imgSize, x = px - y * imgSize;
+        typename VV::T prod = VV::splat(0.f);
+        if (x >= startX && x < lim && y >= startX && y < lim) {
+            int ylo, yhi, xlo, xhi;
+            out_range(y, startX, subsX, strideX, outputsX, ylo, yhi);
+            out_range(x, startX, subsX, strideX, outputsX, xlo, xhi);
+            for (int my = ylo; my < yhi; ++my) {
+                const float ry = fminf((float)imgSize, (float)(startX + my * strideX + subsX)) - fmaxf(0.f, (float)(startX + my * strideX));
+                for (int mx = xlo; mx < xhi; ++mx) {
+                    const float rx = fminf((float)imgSize, (float)(startX + mx * strideX + subsX)) - fmaxf(0.f, (float)(startX + mx * strideX));
+                    const float inv = 1.0f / (rx * ry);  // conv_util.cu:1442
+                    prod = vadd(prod, vscale(VV::ld(avgGrads + ((size_t)c * numOut + my * outputsX + mx) * N + n), inv));
+                }
+            }
+        }
+        float* t = target + (size_t)row * N + n;
+        VV::st(t, sT == 0.f ? vscale(prod, sO) : blend(VV::ld(t), prod, sT, sO));
+    }
+}
+
+// ------------------------------------------------------------------ within-map response / contrast norm
+template <int V>
+__global__ void k_cnorm(const float* __restrict__ imgs, const float* __restrict__ meanDiffs, float* denoms, float* target,
+                        int N, int C, int imgSize, int sizeX, float addScale, float powScale) {
+    typedef Vec<V> VV;
+    const int nChunks = N / V;
+    const int imgPix = imgSize * imgSize;
+    const size_t total = (size_t)C * imgPix * nChunks;
+    for (size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (size_t)gridDim.x * blockDim.x) {
+        int row, n;
+        decode<V>(item, nChunks, row, n);
+        const int c = row / imgPix, px = row - c * imgPix;
+        const int y = px / imgSize, x = px - y * imgSize;
+        const int sy = -sizeX / 2 + y, sx = -sizeX / 2 + x;   // conv_util.cu:844-845
+        const int y0 = max(0, sy), x0 = max(0, sx), y1 = min(imgSize, sy + sizeX), x1 = min(imgSize, sx + sizeX);
+        typename VV::T s = VV::splat(0.f);
+        const float* md = meanDiffs + (size_t)c * imgPix * N + n;
+        for (int yy = y0; yy < y1; ++yy)
+            for (int xx = x0; xx < x1; ++xx) {
+                const typename VV::T v = VV::ld(md + (size_t)(yy * imgSize + xx) * N);
+                s = vadd(s, vmul(v, v));
+            }
+        const typename VV::T d = vfma_s(addScale, s, VV::splat(1.0f));  // 1 + addScale*sum, :889
+        const size_t i = (size_t)row * N + n;
+        VV::st(denoms + i, d);
+        VV::st(target + i, vmul(VV::ld(imgs + i), vpow(d, -powScale)));
+    }
+}
+
+// acts := scale * outGrads * acts / denoms   (kRNormUndoPrelims, conv_util.cu:1603-1615)
+template <int V>
+__global__ void k_rnorm_undo_prelims(float* acts, const float* __restrict__ denoms, const float* __restrict__ outGrads,
+                                     size_t n, float scale) {
+    typedef Vec<V> VV;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * blockDim.x * V)
+        VV::st(acts + i, vdiv(vmul(vscale(VV::ld(outGrads + i), scale), VV::ld(acts + i)), VV::ld(denoms + i)));
+}
+
+template <int V>
+__global__ void k_rnorm_undo(const float* __restrict__ outGrads, const float* __restrict__ denoms,
+                             const float* __restrict__ inputs, const float* __restrict__ acts, float* target, int N, int C,
+                             int imgSize, int sizeX, float powScale, float sT, float sO) {
+    typedef Vec<V> VV;
+    const int nChunks = N / V;
+    const int imgPix = imgSize * imgSize;
+    const size_t total = (size_t)C * imgPix * nChunks;
+    for (size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (size_t)gridDim.x * blockDim.x) {
+        int row, n;
+        decode<V>(item, nChunks, row, n);
+        const int c = row / imgPix, px = row - c * imgPix;
+        const int y = px / imgSize, x = px - y * imgSize;
+        const int y0 = max(0, y + sizeX / 2 - sizeX + 1), x0 = max(0, x + sizeX / 2 - sizeX + 1);  // :1653-1656
+        const int y1 = min(imgSize, y + sizeX / 2 + 1), x1 = min(imgSize, x + sizeX / 2 + 1);
+        typename VV::T s = VV::splat(0.f);
+        const float* a = acts + (size_t)c * imgPix * N + n;
+        for (int yy = y0; yy < y1; ++yy)
+            for (int xx = x0; xx < x1; ++xx) s = vadd(s, VV::ld(a + (size_t)(yy * imgSize + xx) * N));
+        const size_t i = (size_t)row * N + n;
+        // inp * sum + out * den^-pow   (:1697-1701)
+        const typename VV::T v = vadd(vmul(VV::ld(inputs + i), s), vmul(VV::ld(outGrads + i), vpow(VV::ld(denoms + i), -powScale)));
+        VV::st(target + i, sT == 0.f ? vscale(v, sO) : blend(VV::ld(target + i), v, sT, sO));
+    }
+}
+
+// ------------------------------------------------------------------ cross-map response norm
+template <int V>
+__global__ void k_cmrnorm(const float* __restrict__ imgs, float* denoms, float* target, int N, int C, int imgSize, int sizeF,
+                          float addScale, float powScale, int blocked, float k) {
+    typedef Vec<V> VV;
+    const int nChunks = N / V;
+    const int imgPix = imgSize * imgSize;
+    const size_t total = (size_t)C * imgPix * nChunks;
+    for (size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (size_t)gridDim.x * blockDim.x) {
+        int row, n;
+        decode<V>(item, nChunks, row, n);
+        const int c = row / imgPix, px = row - c * imgPix;
+        const int startF = blocked ? (c / sizeF) * sizeF : -sizeF / 2 + c;  // conv_util.cu:1070
+        const int f0 = blocked ? startF : max(0, startF);
+        const int f1 = min(C, startF + sizeF);
+        typename VV::T s = VV::splat(0.f);
+        for (int f = f0; f < f1; ++f) {
+            const typename VV::T v = VV::ld(imgs + ((size_t)f * imgPix + px) * N + n);
+            s = vadd(s, vmul(v, v));
+        }
+        const typename VV::T d = vfma_s(addScale, s, VV::splat(k));  // k + addScale*sum, :1085
+        const size_t i = (size_t)row * N + n;
+        VV::st(denoms + i, d);
+        VV::st(target + i, vmul(VV::ld(imgs + i), vpow(d, -powScale)));
+    }
+}
+
+template <int V>
+__global__ void k_cmrnorm_undo(const float* __restrict__ outGrads, const float* __restrict__ denoms,
+                               const float* __restrict__ inputs, const float* __restrict__ acts, float* target, int N,
+                               int C, int imgSize, int sizeF, float powScale, int blocked, float sT, float sO) {
+    typedef Vec<V> VV;
+    const int nChunks = N / V;
+    const int imgPix = imgSize * imgSize;
+    const size_t total = (size_t)C * imgPix * nChunks;
+    for (size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (size_t)gridDim.x * blockDim.x) {
+        int row, n;
+        decode<V>(item, nChunks, row, n);
+        const int c = row / imgPix, px = row - c * imgPix;
+        const int startF = blocked ? (c / sizeF) * sizeF : -sizeF + sizeF / 2 + 1 + c;  // conv_util.cu:1144
+        const int f0 = blocked ? startF : max(0, startF);
+        const int f1 = min(C, startF + sizeF);
+        typename VV::T s = VV::splat(0.f);
+        for (int f = f0; f < f1; ++f) s = vadd(s, VV::ld(acts + ((size_t)f * imgPix + px) * N + n));
+        const size_t i = (size_t)row * N + n;
+        const typename VV::T v = vadd(vmul(VV::ld(inputs + i), s), vmul(VV::ld(outGrads + i), vpow(VV::ld(denoms + i), -powScale)));
+        VV::st(target + i, sT == 0.f ? vscale(v, sO) : blend(VV::ld(target + i), v, sT, sO));
+    }
+}
+
+inline int grid_items(size_t items) {
+    const size_t want = (items + TPB - 1) / TPB;
+    const size_t cap = (size_t)num_cus() * 16;
+    return (int)(want < 1 ? 1 : (want > cap ? cap : want));
+}
+
+inline bool use_vec(int N, std::initializer_list<const void*> ptrs) {
+    if (N % 4) return false;
+    for (const void* p : ptrs)
+        if (!aligned16(p)) return false;
+    return true;
+}
+
+}  // namespace
+}  // namespace mc
+
+using namespace mc;
+
+#define MC_POOLARGS_OK(who)                                                                                      \
+    MC_REQUIRE(numImages > 0 && numFilters > 0 && imgSize > 0 && subsX > 0 && strideX > 0 && outputsX > 0,      \
+               who ": non-positive dimension");                                                                  \
+    MC_REQUIRE((size_t)numFilters * imgSize * imgSize * numImages < (1ull << 31), who ": tensor exceeds 32-bit indexing")
+
+extern "C" {
+
+int mc_conv_local_pool(const float* images, float* target, int numImages, int numFilters, int imgSize, int subsX,
+                       int startX, int strideX, int outputsX, int pooler, mcStream_t s) {
+    MC_REQUIRE(images && target, "mc_conv_local_pool: null pointer");
+    MC_POOLARGS_OK("mc_conv_local_pool");
+    MC_REQUIRE(pooler == MC_POOL_MAX || pooler == MC_POOL_AVG, "mc_conv_local_pool: unknown pooler %d", pooler);
+    const bool v = use_vec(numImages, {images, target});
+    const size_t items = (size_t)numFilters * outputsX * outputsX * (numImages / (v ? 4 : 1));
+    dim3 g(grid_items(items)), b(TPB);
+#define L(V, MAXP) hipLaunchKernelGGL((k_pool<V, MAXP>), g, b, 0, S(s), images, target, numImages, numFilters, imgSize, subsX, startX, strideX, outputsX)
+    if (pooler == MC_POOL_MAX) { if (v) L(4, true); else L(1, true); }
+    else { if (v) L(4, false); else L(1, false); }
+#undef L
+    return launch_status("mc_conv_local_pool");
+}
+
+int mc_conv_local_max_undo(const float* images, const float* maxGrads, const float* maxActs, float* target, int numImages,
+                           int numFilters, int imgSize, int subsX, int startX, int strideX, int outputsX,
+                           float scaleTargets, float scaleOutput, mcStream_t s) {
+    MC_REQUIRE(images && maxGrads && maxActs && target, "mc_conv_local_max_undo: null pointer");
+    MC_POOLARGS_OK("mc_conv_local_max_undo");
+    const bool v = use_vec(numImages, {images, maxGrads, maxActs, target});
+    const size_t items = (size_t)numFilters * imgSize * imgSize * (numImages / (v ? 4 : 1));
+    dim3 g(grid_items(items)), b(TPB);
+    if (v) hipLaunchKernelGGL(k_max_undo<4>, g, b, 0, S(s), images, maxGrads, maxActs, target, numImages, numFilters, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput);
+    else hipLaunchKernelGGL(k_max_undo<1>, g, b, 0, S(s), images, maxGrads, maxActs, target, numImages, numFilters, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput);
+    return launch_status("mc_conv_local_max_undo");
+}
+
+int mc_conv_local_avg_undo(const float* avgGrads, float* target, int numImages, int numFilters, int imgSize, int subsX,
+                           int startX, int strideX, int outputsX, float scaleTargets, float scaleOutput, mcStream_t s) {
+    MC_REQUIRE(avgGrads && target, "mc_conv_local_avg_undo: null pointer");
+    MC_POOLARGS_OK("mc_conv_local_avg_undo");
+    const bool v = use_vec(numImages, {avgGrads, target});
+    const size_t items = (size_t)numFilters * imgSize * imgSize * (numImages / (v ? 4 : 1));
+    dim3 g(grid_items(items)), b(TPB);
+    if (v) hipLaunchKernelGGL(k_avg_undo<4>, g, b, 0, S(s), avgGrads, target, numImages, numFilters, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput);
+    else hipLaunchKernelGGL(k_avg_undo<1>, g, b, 0, S(s), avgGrads, target, numImages, numFilters, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput);
+    return launch_status("mc_conv_local_avg_undo");
+}
+
+int mc_conv_contrast_norm(const float* images, const float* meanDiffs, float* denoms, float* target, int numImages,
+                          int numFilters, int imgSize, int sizeX, float addScale, float powScale, mcStream_t s) {
+    MC_REQUIRE(images && meanDiffs && denoms && target, "mc_conv_contrast_norm: null pointer");
+    MC_REQUIRE(numImages > 0 && numFilters > 0 && imgSize > 0 && sizeX > 0, "mc_conv_contrast_norm: non-positive dimension");
+    const bool v = use_vec(numImages, {images, meanDiffs, denoms, target});
+    const size_t items = (size_t)numFilters * imgSize * imgSize * (numImages / (v ? 4 : 1));
+    dim3 g(grid_items(items)), b(TPB);
+    if (v) hipLaunchKernelGGL(k_cnorm<4>, g, b, 0, S(s), images, meanDiffs, denoms, target, numImages, numFilters, imgSize, sizeX, addScale, powScale);
+    else hipLaunchKernelGGL(k_cnorm<1>, g, b, 0, S(s), images, meanDiffs, denoms, target, numImages, numFilters, imgSize, sizeX, addScale, powScale);
+    return launch_status("mc_conv_contrast_norm");
+}
+
+int mc_conv_response_norm(const float* images, float* denoms, float* target, int numImages, int numFilters, int imgSize,
+                          int sizeX, float addScale, float powScale, mcStream_t s) {
+    // convResponseNorm passes the images as meanDiffs (conv_util.cu:2074-2076)
+    return mc_conv_contrast_norm(images, images, denoms, target, numImages, numFilters, imgSize, sizeX, addScale, powScale, s);
+}
+
+static int undo_prelims(float* acts, const float* denoms, const float* outGrads, size_t n, float scale, bool v, hipStream_t st) {
+    dim3 g(grid_items(n / (v ? 4 : 1))), b(TPB);
+    if (v) hipLaunchKernelGGL(k_rnorm_undo_prelims<4>, g, b, 0, st, acts, denoms, outGrads, n, scale);
+    else hipLaunchKernelGGL(k_rnorm_undo_prelims<1>, g, b, 0, st, acts, denoms, outGrads, n, scale);
+    return launch_status("rnorm_undo_prelims");
+}
+
+int mc_conv_response_norm_undo(const float* outGrads, const float* denoms, const float* inputs, float* acts, float* target,
+                               int numImages, int numFilters, int imgSize, int sizeX, float addScale, float powScale,
+                               float scaleTargets, float scaleOutput, mcStream_t s) {
+    MC_REQUIRE(outGrads && denoms && inputs && acts && target, "mc_conv_response_norm_undo: null pointer");
+    MC_REQUIRE(numImages > 0 && numFilters > 0 && imgSize > 0 && sizeX > 0, "mc_conv_response_norm_undo: non-positive dimension");
+    const bool v = use_vec(numImages, {outGrads, denoms, inputs, acts, target});
+    const size_t n = (size_t)numFilters * imgSize * imgSize * numImages;
+    int rc = undo_prelims(acts, denoms, outGrads, n, -2 * addScale * powScale, v, S(s));
+    if (rc) return rc;
+    dim3 g(grid_items(n / (v ? 4 : 1))), b(TPB);
+    if (v) hipLaunchKernelGGL(k_rnorm_undo<4>, g, b, 0, S(s), outGrads, denoms, inputs, acts, target, numImages, numFilters, imgSize, sizeX, powScale, scaleTargets, scaleOutput);
+    else hipLaunchKernelGGL(k_rnorm_undo<1>, g, b, 0, S(s), outGrads, denoms, inputs, acts, target, numImages, numFilters, imgSize, sizeX, powScale, scaleTargets, scaleOutput);
+    return launch_status("mc_conv_response_norm_undo");
+}
+
+int mc_conv_response_norm_cross_map(const float* images, float* denoms, float* target, int numImages, int numFilters,
+                                    int imgSize, int sizeF, float addScale, float powScale, int blocked, float k,
+                                    mcStream_t s) {
+    MC_REQUIRE(images && denoms && target, "mc_conv_response_norm_cross_map: null pointer");
+    MC_REQUIRE(numImages > 0 && numFilters > 0 && imgSize > 0 && sizeF > 0 && sizeF <= numFilters, "mc_conv_response_norm_cross_map: bad dimension");
+    const bool v = use_vec(numImages, {images, denoms, target});
+    const size_t items = (size_t)numFilters * imgSize * imgSize * (numImages / (v ? 4 : 1));
+    dim3 g(grid_items(items)), b(TPB);
+    if (v) hipLaunchKernelGGL(k_cmrnorm<4>, g, b, 0, S(s), images, denoms, target, numImages, numFilters, imgSize, sizeF, addScale, powScale, blocked, k);
+    else hipLaunchKernelGGL(k_cmrnorm<1>, g, b, 0, S(s), images, denoms, target, numImages, numFilters, imgSize, sizeF, addScale, powScale, blocked, k);
+    return launch_status("mc_conv_response_norm_cross_map");
+}
+
+int mc_conv_response_norm_cross_map_undo(const float* outGrads, const float* denoms, const float* inputs, float* acts,
+                                         float* target, int numImages, int numFilters, int imgSize, int sizeF,
+                                         float addScale, float powScale, int blocked, float scaleTargets,
+                                         float scaleOutput, mcStream_t s) {
+    MC_REQUIRE(outGrads && denoms && inputs && acts && target, "mc_conv_response_norm_cross_map_undo: null pointer");
+    MC_REQUIRE(numImages > 0 && numFilters > 0 && imgSize > 0 && sizeF > 0 && sizeF <= numFilters, "mc_conv_response_norm_cross_map_undo: bad dimension");
+    const bool v = use_vec(numImages, {outGrads, denoms, inputs, acts, target});
+    const size_t n = (size_t)numFilters * imgSize * imgSize * numImages;
+    int rc = undo_prelims(acts, denoms, outGrads, n, -2 * addScale * powScale, v, S(s));
+    if (rc) return rc;
+    dim3 g(grid_items(n / (v ? 4 : 1))), b(TPB);
+    if (v) hipLaunchKernelGGL(k_cmrnorm_undo<4>, g, b, 0, S(s), outGrads, denoms, inputs, acts, target, numImages, numFilters, imgSize, sizeF, powScale, blocked, scaleTargets, scaleOutput);
+    else hipLaunchKernelGGL(k_cmrnorm_undo<1>, g, b, 0, S(s), outGrads, denoms, inputs, acts, target, numImages, numFilters, imgSize, sizeF, powScale, blocked, scaleTargets, scaleOutput);
+    return launch_status("mc_conv_response_norm_cross_map_undo");
+}
+
+}  // extern "C"

@@ -1,0 +1,223 @@
+/*
+ * mc_kernels.h -- C-ABI of libmckernels.so: the MI355X (gfx950) kernels behind the
+ * cuda-convnet training step.  One entry point per reference host wrapper; the
+ * comment on each cites the wrapper it replaces (paths relative to the reference
+ * tree).  Plain device pointers and sizes only: no C++ types, no torch types.
+ *
+ * Conventions (the reference's, kept):
+ *   - every activation / gradient matrix is float32, row-major (features, numImages),
+ *     i.e. (channel, y, x, image) with the image index innermost
+ *     (Kernel/src/conv/filter_acts.cu:39-43);
+ *   - conv filters are (filterChannels * filterPixels, numFilters) row-major, unshared
+ *     (local) filters (numModules * filterChannels * filterPixels, numFilters);
+ *   - paddingStart <= 0 is the (negated) padding, as the reference passes it
+ *     (Python/layer.py:959);
+ *   - target = scaleTargets * target + scaleOutput * result; scaleTargets == 0 means the
+ *     target is write-only (never read, may hold NaN).
+ *   - all launches are asynchronous on `stream` (a hipStream_t; NULL = default stream).
+ *
+ * Every function returns 0 on success and a negative MC_E* code on a rejected call
+ * (the reference assert()s / exit()s instead: Kernel/include/nvmatrix/nvmatrix.cuh:54-59).
+ * mc_last_error() returns a static description of the last rejection in this thread.
+ */
+#ifndef MC_KERNELS_H
+#define MC_KERNELS_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mcStream_t; /* hipStream_t */
+
+#define MC_OK 0
+#define MC_EINVAL (-1)     /* shape / argument rejected */
+#define MC_ELAUNCH (-2)    /* HIP launch error */
+#define MC_EWORKSPACE (-3) /* workspace too small */
+
+const char* mc_last_error(void);
+/* Library / device identification: returns the gfx arch string of the current device. */
+int mc_device_info(char* archName, int archNameLen, int* numCUs);
+
+/* ---------------- conv / local contractions (fp32 MFMA implicit GEMM) ----------------
+ * Replace Kernel/include/conv/cudaconv2.cuh:36-78:
+ *   convFilterActs  (Kernel/src/conv/filter_acts.cu:2206-2211)
+ *   localFilterActs (filter_acts.cu:2219-2224)
+ *   convImgActs     (Kernel/src/conv/img_acts.cu:2040-2044)
+ *   localImgActs    (img_acts.cu:2051-2056)
+ *   convWeightActs  (Kernel/src/conv/weight_acts.cu:1092-1096)
+ *   localWeightActs (weight_acts.cu:1103-1108)
+ * images (numImgColors*imgSizeY*imgSizeX, numImages); hidActs/targets
+ * (numFilters*numModulesY*numModulesX, numImages).
+ *
+ * mc_conv_filter_acts_fused additionally adds biases[f] (shared biases, the
+ * reshape+addVector of Kernel/src/layers/layer.cu:481-484) and applies `neuron`
+ * (MC_NEURON_NONE / MC_NEURON_RELU) in the epilogue; bit-identical to the unfused sequence.
+ */
+#define MC_NEURON_NONE 0
+#define MC_NEURON_RELU 1
+
+int mc_conv_filter_acts(const float* images, const float* filters, float* targets, int numImages,
+                        int numImgColors, int imgSizeY, int imgSizeX, int numFilters, int filterSize,
+                        int paddingStart, int moduleStride, int numModulesY, int numModulesX,
+                        int numGroups, float scaleTargets, float scaleOutput, mcStream_t stream);
+int mc_conv_filter_acts_fused(const float* images, const float* filters, float* targets,
+                              const float* biases, int neuron, int numImages, int numImgColors,
+                              int imgSizeY, int imgSizeX, int numFilters, int filterSize,
+                              int paddingStart, int moduleStride, int numModulesY, int numModulesX,
+                              int numGroups, float scaleTargets, float scaleOutput, mcStream_t stream);
+int mc_local_filter_acts(const float* images, const float* filters, float* targets, int numImages,
+                         int numImgColors, int imgSizeY, int imgSizeX, int numFilters, int filterSize,
+                         int paddingStart, int moduleStride, int numModulesY, int numModulesX,
+                         int numGroups, float scaleTargets, float scaleOutput, mcStream_t stream);
+int mc_conv_img_acts(const float* hidActs, const float* filters, float* targets, int numImages,
+                     int numImgColors, int imgSizeY, int imgSizeX, int numFilters, int filterSize,
+                     int paddingStart, int moduleStride, int numModulesY, int numModulesX,
+                     int numGroups, float scaleTargets, float scaleOutput, mcStream_t stream);
+int mc_local_img_acts(const float* hidActs, const float* filters, float* targets, int numImages,
+                      int numImgColors, int imgSizeY, int imgSizeX, int numFilters, int filterSize,
+                      int paddingStart, int moduleStride, int numModulesY, int numModulesX,
+                      int numGroups, float scaleTargets, float scaleOutput, mcStream_t stream);
+/* targets: ((numModules/partialSum) * filterChannels*filterPixels, numFilters); chunk q holds
+ * the sum over modules [q*partialSum, (q+1)*partialSum).  partialSum == 0: all modules. */
+int mc_conv_weight_acts(const float* images, const float* hidActs, float* targets, int numImages,
+                        int numImgColors, int imgSizeY, int imgSizeX, int numFilters, int filterSize,
+                        int paddingStart, int moduleStride, int numModulesY, int numModulesX,
+                        int numGroups, int partialSum, float scaleTargets, float scaleOutput,
+                        mcStream_t stream);
+int mc_local_weight_acts(const float* images, const float* hidActs, float* targets, int numImages,
+                         int numImgColors, int imgSizeY, int imgSizeX, int numFilters, int filterSize,
+                         int paddingStart, int moduleStride, int numModulesY, int numModulesX,
+                         int numGroups, float scaleTargets, float scaleOutput, mcStream_t stream);
+/* A partialSum the library considers a good split of the module axis for this shape on this
+ * device (divides numModules; the reference takes it from the layer-def file instead). */
+int mc_conv_weight_acts_pick_partial_sum(int numImages, int numImgColors, int numFilters,
+                                         int filterSize, int numModules, int numGroups);
+
+/* ---------------- dense product ----------------
+ * Replaces NVMatrix::addProduct / rightMult -> cublasSgemm
+ * (Kernel/src/nvmatrix/nvmatrix.cu:189-239), used by FCLayer (Kernel/src/layers/layer.cu:
+ * 373-409) and the cccp plugin (PluginsSrc/src/extralayers.cu:66-174).
+ * Row-major: C(m,n) = scaleTargets*C + scaleOutput * op(A) * op(B); transA: A is stored (k,m);
+ * transB: B is stored (n,k).  lda/ldb/ldc are row strides in floats.
+ * rowBias (nullable) adds rowBias[i] to row i and `neuron` is applied, after the scaling.
+ * workspace (nullable) enables split-K for long k; mc_gemm_workspace_bytes gives the size
+ * the call would like (0 = none needed). */
+size_t mc_gemm_workspace_bytes(int m, int n, int k);
+int mc_gemm(const float* A, const float* B, float* C, int m, int n, int k, int transA, int transB,
+            int lda, int ldb, int ldc, float scaleTargets, float scaleOutput, const float* rowBias,
+            int neuron, void* workspace, size_t workspaceBytes, mcStream_t stream);
+
+/* ---------------- pooling ----------------
+ * convLocalPool<MaxPooler|AvgPooler> (Kernel/include/conv/conv_util.cuh:335-524),
+ * convLocalMaxUndo (Kernel/src/conv/conv_util.cu:1879-1968),
+ * convLocalAvgUndo (conv_util.cu:1978-2072). */
+#define MC_POOL_MAX 0
+#define MC_POOL_AVG 1
+int mc_conv_local_pool(const float* images, float* target, int numImages, int numFilters,
+                       int imgSize, int subsX, int startX, int strideX, int outputsX, int pooler,
+                       mcStream_t stream);
+int mc_conv_local_max_undo(const float* images, const float* maxGrads, const float* maxActs,
+                           float* target, int numImages, int numFilters, int imgSize, int subsX,
+                           int startX, int strideX, int outputsX, float scaleTargets,
+                           float scaleOutput, mcStream_t stream);
+int mc_conv_local_avg_undo(const float* avgGrads, float* target, int numImages, int numFilters,
+                           int imgSize, int subsX, int startX, int strideX, int outputsX,
+                           float scaleTargets, float scaleOutput, mcStream_t stream);
+
+/* ---------------- response normalisation ----------------
+ * convResponseNorm (conv_util.cu:2074-2076), convContrastNorm (:2084-2222),
+ * convResponseNormUndo / convContrastNormUndo (:2224-2424),
+ * convResponseNormCrossMap (:2753-2809, 2902-2904), convResponseNormCrossMapUndo (:2811-2900).
+ * The undo calls OVERWRITE `acts`, as the reference does (conv_util.cu:2236). */
+int mc_conv_response_norm(const float* images, float* denoms, float* target, int numImages,
+                          int numFilters, int imgSize, int sizeX, float addScale, float powScale,
+                          mcStream_t stream);
+int mc_conv_contrast_norm(const float* images, const float* meanDiffs, float* denoms, float* target,
+                          int numImages, int numFilters, int imgSize, int sizeX, float addScale,
+                          float powScale, mcStream_t stream);
+int mc_conv_response_norm_undo(const float* outGrads, const float* denoms, const float* inputs,
+                               float* acts, float* target, int numImages, int numFilters,
+                               int imgSize, int sizeX, float addScale, float powScale,
+                               float scaleTargets, float scaleOutput, mcStream_t stream);
+int mc_conv_response_norm_cross_map(const float* images, float* denoms, float* target,
+                                    int numImages, int numFilters, int imgSize, int sizeF,
+                                    float addScale, float powScale, int blocked, float k,
+                                    mcStream_t stream);
+int mc_conv_response_norm_cross_map_undo(const float* outGrads, const float* denoms,
+                                         const float* inputs, float* acts, float* target,
+                                         int numImages, int numFilters, int imgSize, int sizeF,
+                                         float addScale, float powScale, int blocked,
+                                         float scaleTargets, float scaleOutput, mcStream_t stream);
+
+/* ---------------- neurons ----------------
+ * Neuron functors of Kernel/include/layers/neuron.cuh:120-462 and the dropout neuron of
+ * PluginsSrc/include/extralayers.cuh:34-102.  `a`,`b` are the neuron parameters
+ * (brelu[a], tanh[a,b], linear[a,b], dropout: a = prob).
+ * mc_neuron_input_grad: target = (add ? target : 0) + f'(...)*actsGrad, where `actsOrInputs`
+ * is the neuron's output for relu/brelu/logistic/tanh/softrelu/sqrt and its input for
+ * abs/square (neuron.cuh:255-260, 384-389); ignored for ident/linear. */
+enum {
+    MC_N_IDENT = 0, MC_N_RELU, MC_N_BRELU, MC_N_ABS, MC_N_LOGISTIC, MC_N_TANH, MC_N_SOFTRELU,
+    MC_N_SQUARE, MC_N_SQRT, MC_N_LINEAR
+};
+int mc_neuron_activate(int type, float a, float b, const float* inputs, float* outputs, size_t n,
+                       mcStream_t stream);
+int mc_neuron_input_grad(int type, float a, float b, const float* actsGrad,
+                         const float* actsOrInputs, float* target, int add, size_t n,
+                         mcStream_t stream);
+/* dropout (train): out = mask < prob ? 0 : in; the same rule routes the gradient
+ * (extralayers.cuh:81-96).  `mask` holds uniforms in [0,1).  mc_rand_uniform fills it with a
+ * counter-based (Philox4x32-10) stream: element i depends on (seed, offset + i) only. */
+int mc_dropout_apply(const float* in, const float* mask, float* out, float prob, int add, size_t n,
+                     mcStream_t stream);
+int mc_rand_uniform(float* out, size_t n, unsigned long long seed, unsigned long long offset,
+                    mcStream_t stream);
+
+/* ---------------- generic NVMatrix-style ops ----------------
+ * Replace the NVMatrix element-wise / vector / aggregation kernels on the path
+ * (Kernel/include/nvmatrix/nvmatrix_kernels.cuh): addVector (bias add: layer.cu:376,483),
+ * addSum (bias gradient layer.cu:392,496; partial weight-gradient reduction layer.cu:520),
+ * add/scale (eltsum layer, Weights::update). */
+/* acts(rows, cols) row-major: acts[r][c] += scaleVec * vec[r]  (bias per feature row) */
+int mc_add_row_vector(float* acts, const float* vec, int rows, int cols, float scaleVec,
+                      mcStream_t stream);
+/* out[r] = scaleTargets*out[r] + scaleOutput * sum_c v[r][c] */
+int mc_sum_rows(const float* v, float* out, int rows, int cols, float scaleTargets,
+                float scaleOutput, mcStream_t stream);
+/* out[c] = scaleTargets*out[c] + scaleOutput * sum_r v[r][c]  (fixed summation order) */
+int mc_sum_cols(const float* v, float* out, int rows, int cols, float scaleTargets,
+                float scaleOutput, mcStream_t stream);
+/* y = scaleY*y + scaleX*x */
+int mc_axpby(float* y, const float* x, float scaleY, float scaleX, size_t n, mcStream_t stream);
+/* y = scaleX * x (y may alias x) */
+int mc_scale(float* y, const float* x, float scaleX, size_t n, mcStream_t stream);
+/* out[0] = sum of v[0..n) accumulated in double, fixed order (cost read-back). */
+int mc_sum_all(const float* v, size_t n, double* out, mcStream_t stream);
+
+/* ---------------- softmax / logistic regression cost ----------------
+ * SoftmaxLayer::fpropActs (Kernel/src/layers/layer.cu:612-622, five NVMatrix ops there),
+ * computeLogregCost / computeLogregGrad / computeSoftmaxGrad / computeLogregSoftmaxGrad
+ * (Kernel/src/layers/layer_kernels.cu:198-294).  probs/acts are (numOut, numCases) row-major,
+ * labels (1, numCases) float class indices. */
+int mc_softmax(const float* input, float* target, int numCases, int numOut, mcStream_t stream);
+int mc_compute_logreg_cost(const float* labels, const float* probs, float* labelLogProbs,
+                           float* correctProbs, int numCases, int numOut, mcStream_t stream);
+int mc_compute_logreg_grad(const float* labels, const float* probs, float* target, int add,
+                           float coeff, int numCases, int numOut, mcStream_t stream);
+int mc_compute_softmax_grad(const float* acts, const float* actsGrad, float* target, int add,
+                            int numCases, int numOut, mcStream_t stream);
+int mc_compute_logreg_softmax_grad(const float* labels, const float* probs, float* target, int add,
+                                   float coeff, int numCases, int numOut, mcStream_t stream);
+
+/* ---------------- SGD update ----------------
+ * Weights::update (Kernel/include/layers/weights.cuh:150-164) as one pass:
+ *   inc = mom*inc + grad; if (wc > 0) inc -= wc*eps*W; W += inc. */
+int mc_weights_update(float* weights, float* inc, const float* grad, size_t n, float mom, float eps,
+                      float wc, mcStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MC_KERNELS_H */

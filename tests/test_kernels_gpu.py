@@ -1,0 +1,354 @@
+"""GPU parity: every C-ABI entry point of libmckernels.so against the CPU oracle on the same
+seeded inputs.  Tolerance: fp32 contractions rel 1e-4 (north_star); pooling, max-undo routing,
+relu, dropout and the SGD update are compared exactly."""
+import numpy as np
+import pytest
+
+from oracle import golden as G
+from gpu_util import dev, host, keep, nans, ptr, relerr, zeros
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def mc():
+    import mckernels
+    return mckernels
+
+
+def _modules(img, fs, pad, stride):
+    return 1 + int(np.ceil((2 * pad + img - fs) / float(stride)))
+
+
+# N, C, H, fs, F, pad, stride, groups
+CONV_CASES = [
+    (128, 3, 32, 5, 32, 2, 1, 1),     # layers-80sec conv1
+    (128, 32, 16, 5, 32, 2, 1, 1),    # layers-80sec conv2
+    (128, 32, 8, 5, 64, 2, 1, 1),     # layers-80sec conv3
+    (16, 3, 32, 5, 32, 2, 1, 1),      # 16-case tail minibatch (10000 % 128)
+    (32, 96, 8, 5, 192, 2, 1, 1),     # NIN conv2-like channel/filter counts
+    (64, 192, 8, 3, 192, 1, 1, 1),    # NIN conv3
+    (8, 3, 23, 11, 96, 0, 4, 1),      # imagenet conv1-like: 11x11 stride 4
+    (12, 8, 9, 3, 16, 1, 2, 2),       # groups + stride 2
+    (5, 3, 10, 5, 4, 0, 1, 1),        # odd batch: scalar path; DataGen.m sizes
+    (6, 4, 7, 3, 10, 1, 1, 1),        # filters not a multiple of 4 (cccp6-like F=10)
+    (128, 16, 6, 3, 32, 1, 3, 1),     # stride 3 with padding
+]
+
+
+@pytest.mark.parametrize("N,C,H,fs,F,pad,stride,groups", CONV_CASES)
+def test_conv_triplet(N, C, H, fs, F, pad, stride, groups):
+    m = mc()
+    rng = np.random.default_rng(11)
+    M = _modules(H, fs, pad, stride)
+    fc = C // groups
+    img = rng.standard_normal((C * H * H, N)).astype(np.float32)
+    W = rng.standard_normal((fc * fs * fs, F)).astype(np.float32)
+    hid = rng.standard_normal((F * M * M, N)).astype(np.float32)
+    dimg, dW, dhid = dev(img), dev(W), dev(hid)
+    geo = (N, C, H, H, F, fs, -pad, stride, M, M, groups)
+
+    out = nans(F * M * M, N)
+    m.call("mc_conv_filter_acts", ptr(dimg), ptr(dW), ptr(out), *geo, 0.0, 1.0, None)
+    exp = G.filter_acts(img, W, *geo)
+    assert relerr(host(out), exp) < TOL
+
+    # accumulate form: target = 0.5*target + 2*conv
+    prev = rng.standard_normal(exp.shape).astype(np.float32)
+    out2 = dev(prev)
+    m.call("mc_conv_filter_acts", ptr(dimg), ptr(dW), ptr(out2), *geo, 0.5, 2.0, None)
+    assert relerr(host(out2), 0.5 * prev + 2.0 * exp) < TOL
+
+    din = nans(C * H * H, N)
+    m.call("mc_conv_img_acts", ptr(dhid), ptr(dW), ptr(din), *geo, 0.0, 1.0, None)
+    assert relerr(host(din), G.img_acts(hid, W, *geo)) < TOL
+
+    for ps in sorted({0, 1, M} | ({M * M // 2} if (M * M) % 2 == 0 else set())):
+        if ps and (M * M) % ps:
+            continue
+        expw = G.weight_acts(img, hid, *geo, partial_sum=ps)
+        dw = nans(*expw.shape)
+        m.call("mc_conv_weight_acts", ptr(dimg), ptr(dhid), ptr(dw), *geo, ps, 0.0, 1.0, None)
+        assert relerr(host(dw), expw) < TOL, ps
+
+
+def test_conv_fused_bias_relu_is_bitwise_unfused():
+    m = mc()
+    rng = np.random.default_rng(12)
+    N, C, H, fs, F, pad, stride = 128, 3, 32, 5, 32, 2, 1
+    M = _modules(H, fs, pad, stride)
+    geo = (N, C, H, H, F, fs, -pad, stride, M, M, 1)
+    img, W = dev(rng.standard_normal((C * H * H, N))), dev(rng.standard_normal((C * fs * fs, F)))
+    b = dev(rng.standard_normal((F,)))
+    a = nans(F * M * M, N)
+    m.call("mc_conv_filter_acts", ptr(img), ptr(W), ptr(a), *geo, 0.0, 1.0, None)
+    m.call("mc_add_row_vector", ptr(a), ptr(b), F, M * M * N, 1.0, None)
+    m.call("mc_neuron_activate", m.NEURONS["relu"], 0.0, 0.0, ptr(a), ptr(a), a.numel(), None)
+    f = nans(F * M * M, N)
+    m.call("mc_conv_filter_acts_fused", ptr(img), ptr(W), ptr(f), ptr(b), m.NEURON_RELU, *geo, 0.0, 1.0, None)
+    assert np.array_equal(host(a), host(f))
+
+
+LOCAL_CASES = [(128, 64, 8, 3, 32, 1, 1, 1), (16, 32, 8, 3, 32, 1, 1, 1), (6, 16, 7, 5, 32, 2, 3, 2), (5, 4, 6, 3, 6, 1, 1, 1)]
+
+
+@pytest.mark.parametrize("N,C,H,fs,F,pad,stride,groups", LOCAL_CASES)
+def test_local_triplet(N, C, H, fs, F, pad, stride, groups):
+    m = mc()
+    rng = np.random.default_rng(13)
+    M = _modules(H, fs, pad, stride)
+    fc = C // groups
+    img = rng.standard_normal((C * H * H, N)).astype(np.float32)
+    W = rng.standard_normal((M * M * fc * fs * fs, F)).astype(np.float32)
+    hid = rng.standard_normal((F * M * M, N)).astype(np.float32)
+    dimg, dW, dhid = dev(img), dev(W), dev(hid)
+    geo = (N, C, H, H, F, fs, -pad, stride, M, M, groups)
+    out = nans(F * M * M, N)
+    m.call("mc_local_filter_acts", ptr(dimg), ptr(dW), ptr(out), *geo, 0.0, 1.0, None)
+    assert relerr(host(out), G.filter_acts(img, W, *geo, conv=False)) < TOL
+    din = nans(C * H * H, N)
+    m.call("mc_local_img_acts", ptr(dhid), ptr(dW), ptr(din), *geo, 0.0, 1.0, None)
+    assert relerr(host(din), G.img_acts(hid, W, *geo, conv=False)) < TOL
+    expw = G.weight_acts(img, hid, *geo, conv=False)
+    prev = rng.standard_normal(expw.shape).astype(np.float32)
+    dw = dev(prev)   # the reference accumulates straight into weightsInc with beta = momentum (layer.cu:578-591)
+    m.call("mc_local_weight_acts", ptr(dimg), ptr(dhid), ptr(dw), *geo, 0.9, 0.01, None)
+    assert relerr(host(dw), 0.9 * prev + 0.01 * expw) < TOL
+
+
+GEMM_CASES = [  # m, n, k
+    (160, 1024 * 16, 192), (96, 4096, 160), (10, 8192, 192), (64, 128, 1024), (10, 128, 64),
+    (192, 192, 4096), (37, 53, 29), (2048, 128, 2560),
+]
+
+
+@pytest.mark.parametrize("m_,n_,k_", GEMM_CASES)
+@pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_gemm(m_, n_, k_, ta, tb):
+    m = mc()
+    rng = np.random.default_rng(14)
+    A = rng.standard_normal((k_, m_) if ta else (m_, k_)).astype(np.float32)
+    B = rng.standard_normal((n_, k_) if tb else (k_, n_)).astype(np.float32)
+    exp = G.matmul(A.T if ta else A, B.T if tb else B)
+    dA, dB = dev(A), dev(B)
+    C = nans(m_, n_)
+    ws_bytes = m.lib().mc_gemm_workspace_bytes(m_, n_, k_)
+    ws = zeros(max(1, ws_bytes // 4))
+    m.call("mc_gemm", ptr(dA), ptr(dB), ptr(C), m_, n_, k_, ta, tb, A.shape[1], B.shape[1], n_, 0.0, 1.0, None,
+           m.NEURON_NONE, ptr(ws), ws_bytes, None)
+    assert relerr(host(C), exp) < TOL
+    # beta/alpha + bias + relu epilogue, no workspace
+    prev = rng.standard_normal((m_, n_)).astype(np.float32)
+    bias = rng.standard_normal((m_,)).astype(np.float32)
+    C2, db = dev(prev), dev(bias)
+    m.call("mc_gemm", ptr(dA), ptr(dB), ptr(C2), m_, n_, k_, ta, tb, A.shape[1], B.shape[1], n_, 0.25, 0.5, ptr(db),
+           m.NEURON_RELU, None, 0, None)
+    e2 = np.maximum(0.25 * prev + 0.5 * exp.astype(np.float64) + bias[:, None], 0)
+    assert relerr(host(C2), e2) < TOL
+
+
+POOL_CASES = [  # N, C, S, size, start, stride
+    (128, 96, 32, 3, 0, 2), (128, 10, 8, 8, 0, 1), (16, 32, 16, 3, 0, 2), (128, 16, 8, 2, 1, 2),
+    (6, 16, 6, 4, -2, 4), (5, 3, 7, 3, 0, 2),
+]
+
+
+@pytest.mark.parametrize("N,C,S,size,start,stride", POOL_CASES)
+@pytest.mark.parametrize("kind", ["max", "avg"])
+def test_pool_and_undo(N, C, S, size, start, stride, kind):
+    m = mc()
+    rng = np.random.default_rng(15)
+    outX = int(np.ceil((S - start - size) / float(stride))) + 1
+    x = rng.standard_normal((C * S * S, N)).astype(np.float32)
+    if kind == "max":   # ReLU-like zero plateaus exercise the equality (tie) routing
+        x = np.maximum(x, 0)
+    dx = dev(x)
+    y = nans(C * outX * outX, N)
+    m.call("mc_conv_local_pool", ptr(dx), ptr(y), N, C, S, size, start, stride, outX, m.POOL_MAX if kind == "max" else m.POOL_AVG, None)
+    ey = G.pool(x, N, C, S, size, start, stride, outX, kind)
+    assert np.array_equal(host(y), ey)            # bit exact (same fp32 order)
+    g = rng.standard_normal(ey.shape).astype(np.float32)
+    dg = dev(g)
+    prev = rng.standard_normal(x.shape).astype(np.float32)
+    for sT, sO in ((0.0, 1.0), (1.0, 1.0)):
+        t = nans(*x.shape) if sT == 0 else dev(prev)
+        if kind == "max":
+            m.call("mc_conv_local_max_undo", ptr(dx), ptr(dg), ptr(y), ptr(t), N, C, S, size, start, stride, outX, sT, sO, None)
+            e = G.max_undo(x, g, ey, N, C, S, size, start, stride, outX, target=prev.copy(), scale_targets=sT, scale_output=sO)
+            assert np.array_equal(host(t), e)     # routing bit exact
+        else:
+            m.call("mc_conv_local_avg_undo", ptr(dg), ptr(t), N, C, S, size, start, stride, outX, sT, sO, None)
+            e = G.avg_undo(g, N, C, S, size, start, stride, outX, target=prev.copy(), scale_targets=sT, scale_output=sO)
+            np.testing.assert_allclose(host(t), e, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("N,C,S,size", [(128, 32, 16, 3), (16, 32, 8, 3), (6, 16, 5, 5), (5, 16, 6, 9)])
+def test_rnorm_and_undo(N, C, S, size):
+    m = mc()
+    rng = np.random.default_rng(16)
+    scale, pw = 0.001 / size ** 2, 0.75
+    x = rng.standard_normal((C * S * S, N)).astype(np.float32) * 3
+    dx, den, y = dev(x), nans(*x.shape), nans(*x.shape)
+    m.call("mc_conv_response_norm", ptr(dx), ptr(den), ptr(y), N, C, S, size, scale, pw, None)
+    ey, eden = G.rnorm(x, N, C, S, size, scale, pw)
+    assert relerr(host(den), eden) < 1e-6 and relerr(host(y), ey) < TOL
+    g = rng.standard_normal(x.shape).astype(np.float32)
+    t = nans(*x.shape)
+    acts = dev(ey)
+    m.call("mc_conv_response_norm_undo", ptr(keep(dev(g))), ptr(keep(dev(eden))), ptr(dx), ptr(acts), ptr(t), N, C, S, size, scale, pw, 0.0, 1.0, None)
+    eacts = ey.copy()
+    e = G.rnorm_undo(g, eden, x, eacts, N, C, S, size, scale, pw)
+    assert relerr(host(t), e) < TOL
+    assert relerr(host(acts), eacts) < TOL          # acts is clobbered the same way (conv_util.cu:2236)
+
+
+@pytest.mark.parametrize("N,C,S,size,blocked", [(128, 96, 6, 5, 0), (16, 32, 4, 5, 0), (6, 16, 3, 4, 1), (5, 16, 3, 3, 0)])
+def test_cmrnorm_and_undo(N, C, S, size, blocked):
+    m = mc()
+    rng = np.random.default_rng(17)
+    scale, pw, k = 0.0001 / size, 0.75, 2.0
+    x = rng.standard_normal((C * S * S, N)).astype(np.float32) * 5
+    dx, den, y = dev(x), nans(*x.shape), nans(*x.shape)
+    m.call("mc_conv_response_norm_cross_map", ptr(dx), ptr(den), ptr(y), N, C, S, size, scale, pw, blocked, k, None)
+    ey, eden = G.cmrnorm(x, N, C, S, size, scale, pw, bool(blocked), k)
+    assert relerr(host(den), eden) < 1e-6 and relerr(host(y), ey) < TOL
+    g = rng.standard_normal(x.shape).astype(np.float32)
+    prev = rng.standard_normal(x.shape).astype(np.float32)
+    t = dev(prev)
+    acts = dev(ey)
+    m.call("mc_conv_response_norm_cross_map_undo", ptr(keep(dev(g))), ptr(keep(dev(eden))), ptr(dx), ptr(acts), ptr(t), N, C, S, size, scale, pw, blocked, 1.0, 1.0, None)
+    e = G.cmrnorm_undo(g, eden, x, ey.copy(), N, C, S, size, scale, pw, bool(blocked), target=prev.copy(), scale_targets=1.0, scale_output=1.0)
+    assert relerr(host(t), e) < TOL
+
+
+NEURON_CASES = [("ident", {}), ("relu", {}), ("brelu", {"a": 0.7}), ("abs", {}), ("logistic", {}),
+                ("tanh", {"a": 1.79, "b": -0.66}), ("softrelu", {}), ("square", {}), ("sqrt", {}), ("linear", {"a": 3.0, "b": 2.2})]
+
+
+@pytest.mark.parametrize("kind,params", NEURON_CASES)
+@pytest.mark.parametrize("n", [4096 * 3, 1001])
+def test_neurons(kind, params, n):
+    m = mc()
+    rng = np.random.default_rng(18)
+    x = rng.standard_normal(n).astype(np.float32) * 3
+    if kind == "sqrt":
+        x = np.abs(x) + 0.1
+    a, b = params.get("a", 0.0), params.get("b", 0.0)
+    dx, y = dev(x), nans(n)
+    m.call("mc_neuron_activate", m.NEURONS[kind], a, b, ptr(dx), ptr(y), n, None)
+    ey = G.neuron_fwd(kind, params, x)
+    exact = kind in ("ident", "relu", "brelu", "abs", "square")   # linear: a*x+b is one FMA on the GPU
+    if exact:
+        assert np.array_equal(host(y), ey)
+    else:
+        np.testing.assert_allclose(host(y), ey, rtol=2e-6, atol=1e-6)
+    g = rng.standard_normal(n).astype(np.float32)
+    uses_input = kind in ("abs", "square")
+    eg = G.neuron_bwd(kind, params, g, ey, x)
+    for add in (0, 1):
+        prev = rng.standard_normal(n).astype(np.float32)
+        t = dev(prev)
+        m.call("mc_neuron_input_grad", m.NEURONS[kind], a, b, ptr(keep(dev(g))), ptr(dx if uses_input else keep(dev(ey))), ptr(t), add, n, None)
+        np.testing.assert_allclose(host(t), eg + (prev if add else 0), rtol=1e-5, atol=1e-5)
+    # in-place activation (actsTarget >= 0 layers run the neuron in place, layer.cu:97)
+    m.call("mc_neuron_activate", m.NEURONS[kind], a, b, ptr(dx), ptr(dx), n, None)
+    np.testing.assert_allclose(host(dx), ey, rtol=2e-6, atol=1e-6)
+
+
+def test_dropout_and_rng():
+    m = mc()
+    n = 128 * 96 * 16 * 16
+    u = zeros(n)
+    m.call("mc_rand_uniform", ptr(u), n, 99, 0, None)
+    hu = host(u)
+    assert hu.min() >= 0.0 and hu.max() < 1.0 and abs(hu.mean() - 0.5) < 2e-3 and abs((hu < 0.5).mean() - 0.5) < 2e-3
+    # counter based: a sub-range regenerated with its offset is the same stream
+    v = zeros(1000)
+    m.call("mc_rand_uniform", ptr(v), 1000, 99, 4096, None)
+    assert np.array_equal(host(v), hu[4096:5096])
+    w = zeros(1000)
+    m.call("mc_rand_uniform", ptr(w), 1000, 100, 4096, None)
+    assert not np.array_equal(host(w), host(v))
+    rng = np.random.default_rng(19)
+    x = rng.standard_normal(n).astype(np.float32)
+    y = nans(n)
+    m.call("mc_dropout_apply", ptr(keep(dev(x))), ptr(u), ptr(y), 0.5, 0, n, None)
+    assert np.array_equal(host(y), G.neuron_fwd("dropout", {"prob": 0.5}, x, train=True, mask=hu))
+
+
+def test_bias_and_reductions():
+    m = mc()
+    rng = np.random.default_rng(20)
+    for rows, cols in ((192, 16 * 16 * 128), (10, 64 * 16), (7, 33)):
+        a = rng.standard_normal((rows, cols)).astype(np.float32)
+        b = rng.standard_normal(rows).astype(np.float32)
+        da = dev(a)
+        m.call("mc_add_row_vector", ptr(da), ptr(keep(dev(b))), rows, cols, 1.0, None)
+        assert np.array_equal(host(da), a + b[:, None])
+        prev = rng.standard_normal(rows).astype(np.float32)
+        o = dev(prev)
+        m.call("mc_sum_rows", ptr(keep(dev(a))), ptr(o), rows, cols, 0.5, 0.01, None)
+        np.testing.assert_allclose(host(o), 0.5 * prev + 0.01 * a.astype(np.float64).sum(1), rtol=1e-5, atol=1e-5)
+        o2 = nans(cols)
+        m.call("mc_sum_cols", ptr(keep(dev(a))), ptr(o2), rows, cols, 0.0, 1.0, None)
+        np.testing.assert_allclose(host(o2), a.astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
+    import torch
+    v = rng.standard_normal(128).astype(np.float32)
+    out = torch.zeros(1, dtype=torch.float64, device="cuda")
+    m.call("mc_sum_all", ptr(keep(dev(v))), 128, out.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert abs(out.item() - v.astype(np.float64).sum()) < 1e-9
+
+
+@pytest.mark.parametrize("N,K", [(128, 10), (16, 10), (128, 100), (5, 7)])
+def test_softmax_logreg(N, K):
+    m = mc()
+    rng = np.random.default_rng(21)
+    x = (rng.standard_normal((K, N)) * 4).astype(np.float32)
+    labels = rng.integers(0, K, size=(1, N)).astype(np.float32)
+    dx, dl = dev(x), dev(labels)
+    p = nans(K, N)
+    m.call("mc_softmax", ptr(dx), ptr(p), N, K, None)
+    ep = G.softmax(x)
+    np.testing.assert_allclose(host(p), ep, rtol=1e-5, atol=1e-7)
+    hp = host(p)
+    lp, cp = nans(N), nans(N)
+    m.call("mc_compute_logreg_cost", ptr(dl), ptr(p), ptr(lp), ptr(cp), N, K, None)
+    ec = G.logreg_cost(labels, hp)
+    assert abs(-host(lp).astype(np.float64).sum() - ec[0]) < 1e-4 * max(1.0, abs(ec[0]))
+    assert abs((N - host(cp).astype(np.float64).sum()) - ec[1]) < 1e-6
+    g = nans(K, N)
+    m.call("mc_compute_logreg_softmax_grad", ptr(dl), ptr(p), ptr(g), 0, 0.1, N, K, None)
+    np.testing.assert_allclose(host(g), G.logreg_softmax_grad(labels, hp, 0.1), rtol=1e-6, atol=1e-7)
+    g2 = nans(K, N)
+    m.call("mc_compute_logreg_grad", ptr(dl), ptr(p), ptr(g2), 0, 1.0, N, K, None)
+    np.testing.assert_allclose(host(g2), G.logreg_grad(labels, hp, 1.0), rtol=1e-6)
+    g3 = nans(K, N)
+    m.call("mc_compute_softmax_grad", ptr(p), ptr(g2), ptr(g3), 0, N, K, None)
+    np.testing.assert_allclose(host(g3), G.softmax_grad(hp, host(g2)), rtol=1e-4, atol=1e-5)
+
+
+def test_weights_update():
+    m = mc()
+    rng = np.random.default_rng(22)
+    for n in (2400 * 192, 1001):
+        w, inc, grad = (rng.standard_normal(n).astype(np.float32) for _ in range(3))
+        for wc in (0.0, 0.004):
+            dw, di = dev(w), dev(inc)
+            m.call("mc_weights_update", ptr(dw), ptr(di), ptr(keep(dev(grad))), n, 0.9, 0.001, wc, None)
+            ew, ei = w.copy(), inc.copy()
+            G.sgd_update(ew, ei, grad, 0.001, wc, 0.9)
+            # mom*inc+grad contracts to one FMA on the GPU (as nvcc does for the reference): 1-ulp tolerance
+            np.testing.assert_allclose(host(di), ei, rtol=2e-6, atol=1e-6)
+            np.testing.assert_allclose(host(dw), ew, rtol=2e-6, atol=1e-6)
+
+
+def test_rejected_calls_report():
+    m = mc()
+    with pytest.raises(m.McError):
+        m.call("mc_conv_filter_acts", None, None, None, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 0.0, 1.0, None)
+    x = zeros(16)
+    with pytest.raises(m.McError, match="partialSum"):
+        m.call("mc_conv_weight_acts", ptr(x), ptr(x), ptr(x), 4, 1, 2, 2, 1, 1, 0, 1, 2, 2, 1, 3, 0.0, 1.0, None)
+    with pytest.raises(m.McError, match="paddingStart"):
+        m.call("mc_conv_filter_acts", ptr(x), ptr(x), ptr(x), 4, 1, 2, 2, 1, 1, 1, 1, 2, 2, 1, 0.0, 1.0, None)
