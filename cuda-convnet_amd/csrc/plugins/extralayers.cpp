@@ -1,0 +1,136 @@
+// extralayers.cpp -> Plugins/extralayers.so : the NIN plugin.
+//   layer  "cccp"    : cascaded cross-channel parametric pooling (a 1x1 convolution over feature
+//                      maps), reference PluginsSrc/src/extralayers.cu:58-174
+//   neuron "dropout" : reference PluginsSrc/include/extralayers.cuh:34-102
+// Exports the two plugin entry points of the reference (extralayers.cu:200-215).  The
+// cost.gsinlabel layer of the reference's plugin is not provided (no shipped config uses it).
+#include <iostream>
+
+#include "../runtime/convnet.h"
+
+using namespace rt;
+
+static inline mcStream_t ST() { return reinterpret_cast<mcStream_t>(computeStream()); }
+
+// Input viewed as (channels*in_nodes, pixels*numCases): feature f = (ch*in_nodes + i)*pixels + p,
+// which is how the reference's reshape of the (numCases, features) column-major matrix groups
+// it (extralayers.cu:70-79).  Per channel slice: Y(out, P*N) = W(out, in) * X(in, P*N) + b.
+class CCCPLayer : public WeightLayer {
+public:
+    CCCPLayer(ConvNet* convNet, PyObject* paramsDict) : WeightLayer(convNet, paramsDict, true) {
+        _wStep = 0.1f;
+        _bStep = 0.01f;
+        _channels = pyDictGetInt(paramsDict, "channels");
+        _in = pyDictGetInt(paramsDict, "in_nodes");
+        _out = pyDictGetInt(paramsDict, "out_nodes");
+        if (_channels <= 0 || _in <= 0 || _out <= 0) throw std::runtime_error("cccp: channels, in_nodes, out_nodes must be positive");
+    }
+
+protected:
+    int pixels(int inputFeatures) const {
+        if (inputFeatures % (_channels * _in) != 0) throw std::runtime_error(fmt("cccp layer '%s': %d input features are not a multiple of channels*in_nodes = %d", _name.c_str(), inputFeatures, _channels * _in));
+        return inputFeatures / (_channels * _in);
+    }
+
+    void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE) override {
+        const int N = numCases(), P = pixels(_inputs[inpIdx]->rows()), cols = P * N;
+        NeuronLayer* relu = fusableRelu();
+        if (relu) relu->setFusedIntoProducer(true);
+        const size_t wsb = mc_gemm_workspace_bytes(_out, cols, _in);
+        for (int ch = 0; ch < _channels; ch++) {
+            const float* W = _weights[inpIdx].getW() + (size_t)ch * _out * _in;
+            const float* X = _inputs[inpIdx]->data() + (size_t)ch * _in * cols;
+            float* Y = getActs().data() + (size_t)ch * _out * cols;
+            RT_MC(mc_gemm(W, X, Y, _out, cols, _in, 0, 0, _in, cols, cols, scaleTargets, 1.f, scaleTargets == 0 ? _biases->getW() + ch * _out : nullptr,
+                          relu ? MC_NEURON_RELU : MC_NEURON_NONE, wsb ? workspace(wsb) : nullptr, wsb, ST()));
+        }
+    }
+
+    void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE) override {
+        const int N = numCases(), P = pixels(_prev[inpIdx]->getNumOutputs()), cols = P * N;
+        const size_t wsb = mc_gemm_workspace_bytes(_in, cols, _out);
+        for (int ch = 0; ch < _channels; ch++) {
+            const float* W = _weights[inpIdx].getW() + (size_t)ch * _out * _in;
+            const float* G = v.data() + (size_t)ch * _out * cols;
+            float* dX = _prev[inpIdx]->getActsGrad().data() + (size_t)ch * _in * cols;
+            RT_MC(mc_gemm(W, G, dX, _in, cols, _out, 1, 0, _in, cols, cols, scaleTargets, 1.f, nullptr, MC_NEURON_NONE, wsb ? workspace(wsb) : nullptr, wsb, ST()));
+        }
+    }
+
+    void bpropBiases(DevMat& v, PASS_TYPE passType) override {
+        // the sum runs over pixels and cases, the scale is still eps / numCases (extralayers.cu:130-138)
+        const int N = numCases(), P = v.rows() / (_channels * _out);
+        const float scale = passType == PASS_GC ? 1.f : _biases->getEps() / _convNet->gradScaleCases(N);
+        RT_MC(mc_sum_rows(v.data(), _biases->getGrad(), _channels * _out, P * N, 0.f, scale, ST()));
+    }
+
+    void bpropWeights(DevMat& v, int inpIdx, PASS_TYPE passType) override {
+        const int N = numCases(), P = pixels(_prev[inpIdx]->getNumOutputs()), cols = P * N;
+        const float scale = passType == PASS_GC ? 1.f : _weights[inpIdx].getEps() / _convNet->gradScaleCases(N);
+        const float scaleTargets = _weights[inpIdx].getNumUpdates() > 0 ? 1.f : 0.f;
+        const size_t wsb = mc_gemm_workspace_bytes(_out, _in, cols);
+        for (int ch = 0; ch < _channels; ch++) {
+            const float* G = v.data() + (size_t)ch * _out * cols;
+            const float* X = _prev[inpIdx]->getActs().data() + (size_t)ch * _in * cols;
+            float* dW = _weights[inpIdx].getGrad() + (size_t)ch * _out * _in;
+            // dW(out, in) = G(out, P*N) * X(in, P*N)^T
+            RT_MC(mc_gemm(G, X, dW, _out, _in, cols, 0, 1, cols, cols, _in, scaleTargets, scale, nullptr, MC_NEURON_NONE, wsb ? workspace(wsb) : nullptr, wsb, ST()));
+        }
+    }
+
+    int _channels, _in, _out;
+};
+
+// train: y = u < p ? 0 : x with a fresh uniform mask, the same mask routes the gradient;
+// test and gradient check: y = (1 - p) * x.  No 1/(1-p) rescale at train time.
+class DropoutNeuron : public Neuron {
+public:
+    explicit DropoutNeuron(PyObject* neuronParamsDict) {
+        _prob = pyDictGetFloat(neuronParamsDict, "prob");
+        if (!(_prob > 0 && _prob < 1)) throw std::runtime_error("dropout probability must be in (0, 1)");
+    }
+
+    void activate(DevMat& inputs, DevMat& outputs, PASS_TYPE passType) override {
+        _activated = true;
+        _inputs = &inputs;
+        _outputs = &outputs;
+        if (&inputs != &outputs) outputs.resize(inputs);
+        if (passType == PASS_TRAIN) {
+            _mask.resize(inputs);
+            fillUniform(_mask);
+            RT_MC(mc_dropout_apply(inputs.data(), _mask.data(), outputs.data(), _prob, 0, inputs.numel(), ST()));
+        } else {
+            RT_MC(mc_scale(outputs.data(), inputs.data(), 1.f - _prob, inputs.numel(), ST()));
+        }
+    }
+
+    void computeInputGrad(DevMat& actsGrad, DevMat& target, bool add, PASS_TYPE passType) override {
+        if (!add && &target != &actsGrad) target.resize(actsGrad);
+        if (passType == PASS_TRAIN) {
+            RT_MC(mc_dropout_apply(actsGrad.data(), _mask.data(), target.data(), _prob, add ? 1 : 0, actsGrad.numel(), ST()));
+        } else if (add) {
+            RT_MC(mc_axpby(target.data(), actsGrad.data(), 1.f, 1.f - _prob, actsGrad.numel(), ST()));
+        } else {
+            RT_MC(mc_scale(target.data(), actsGrad.data(), 1.f - _prob, actsGrad.numel(), ST()));
+        }
+    }
+
+private:
+    DevMat _mask;
+    float _prob;
+};
+
+static Layer* CreateCCCPLayer(ConvNet* convNet, PyObject* paramsDict) { return new CCCPLayer(convNet, paramsDict); }
+static Neuron* CreateDropoutNeuron(PyObject* neuronParamsDict) { return new DropoutNeuron(neuronParamsDict); }
+
+extern "C" __attribute__((visibility("default"))) std::map<std::string, layerConFunc> layerConstructor() {
+    std::map<std::string, layerConFunc> ret;
+    ret["cccp"] = &CreateCCCPLayer;
+    return ret;
+}
+
+extern "C" __attribute__((visibility("default"))) std::map<std::string, neuronConFunc> neuronConstructor() {
+    std::map<std::string, neuronConFunc> ret;
+    ret["dropout"] = &CreateDropoutNeuron;
+    return ret;
+}

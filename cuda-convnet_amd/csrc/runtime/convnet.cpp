@@ -1,0 +1,686 @@
+// convnet.cpp -- model object, device thread, data staging, cost read-back, gradient check,
+// work items, gradient all-reduce.  Reference: Kernel/src/convnet/convnet.cu, worker.cu,
+// Kernel/src/data/data.cu (cited per block).
+#include "convnet.h"
+
+#include <dlfcn.h>
+#include <math.h>
+#include <string.h>
+#include <time.h>
+
+#include <algorithm>
+#include <deque>
+#include <functional>
+#include <iostream>
+
+namespace rt {
+
+static inline mcStream_t ST() { return reinterpret_cast<mcStream_t>(computeStream()); }
+
+// ==========================================================================================
+// random numbers for stochastic neurons
+// ==========================================================================================
+namespace {
+std::mutex g_randMutex;
+std::deque<std::vector<float>> g_injected;
+unsigned long long g_seed = 0, g_offset = 0;
+bool g_seeded = false;
+}  // namespace
+
+void setRandSeed(unsigned long long seed) {
+    std::lock_guard<std::mutex> g(g_randMutex);
+    g_seed = seed;
+    g_offset = 0;
+    g_seeded = true;
+}
+
+void injectUniform(const float* host, size_t n) {
+    std::lock_guard<std::mutex> g(g_randMutex);
+    g_injected.emplace_back(host, host + n);
+}
+
+void fillUniform(DevMat& m) {
+    std::unique_lock<std::mutex> g(g_randMutex);
+    if (!g_injected.empty()) {
+        std::vector<float> mask;
+        mask.swap(g_injected.front());
+        g_injected.pop_front();
+        g.unlock();
+        if (mask.size() != m.numel()) throw std::runtime_error(fmt("injected mask has %zu elements, the layer needs %zu", mask.size(), m.numel()));
+        RT_HIP(hipMemcpyAsync(m.data(), mask.data(), mask.size() * sizeof(float), hipMemcpyHostToDevice, computeStream()));
+        RT_HIP(hipStreamSynchronize(computeStream()));   // `mask` dies at scope exit
+        return;
+    }
+    if (!g_seeded) {
+        g_seed = (unsigned long long)time(nullptr);
+        g_seeded = true;
+    }
+    const unsigned long long off = g_offset;
+    g_offset += m.numel();
+    g.unlock();
+    RT_MC(mc_rand_uniform(m.data(), m.numel(), g_seed, off, ST()));
+}
+
+// ==========================================================================================
+// Cost
+// ==========================================================================================
+void Cost::add(const std::string& name, float coeff, const double* vals, int n) {
+    std::vector<double>& v = _costMap[name];
+    if ((int)v.size() < n) v.resize(n, 0.0);
+    for (int i = 0; i < n; ++i) v[i] += vals[i];
+    _coeffs[name] = coeff;
+}
+
+double Cost::getValue() const {
+    double val = 0;
+    for (auto& kv : _costMap) val += _coeffs.at(kv.first) * kv.second.at(0);
+    return val;
+}
+
+// ==========================================================================================
+// DataProvider                                                             (data.cu:32-121)
+// ==========================================================================================
+DataProvider::~DataProvider() {
+    for (DevMat* m : _data) delete m;
+    for (DevMat* m : _mini) delete m;
+}
+
+void DataProvider::setData(HostMatV& hData) {
+    _hData = &hData;
+    if (hData.empty()) throw std::runtime_error("empty data list");
+    const int cases = hData[0]->cols();
+    for (size_t i = 0; i < hData.size(); i++) {
+        if (hData[i]->fortran()) throw std::runtime_error("data matrices must be C-ordered (dims, cases)");
+        if (hData[i]->cols() != cases) throw std::runtime_error("data matrices disagree on the number of cases");
+        if (i >= _data.size()) {
+            _data.push_back(new DevMat());
+            _mini.push_back(new DevMat());
+        }
+        _data[i]->copyFromHost(hData[i]->data(), hData[i]->rows(), hData[i]->cols());
+    }
+}
+
+int DataProvider::getNumCases() const {
+    if (_data.empty() || _data[0]->cols() <= 0) throw std::runtime_error("no data on the device");
+    return _data[0]->cols();
+}
+
+int DataProvider::getNumMinibatches() const { return (getNumCases() + _minibatchSize - 1) / _minibatchSize; }
+
+int DataProvider::getNumCasesInMinibatch(int idx) const {
+    return std::min(_minibatchSize, std::max(0, getNumCases() - idx * _minibatchSize));
+}
+
+DevMatV& DataProvider::getMinibatch(int idx) {
+    if (idx < 0 || idx >= getNumMinibatches()) throw std::runtime_error(fmt("minibatch %d out of range", idx));
+    return getDataSlice(idx * _minibatchSize, (idx + 1) * _minibatchSize);
+}
+
+DevMatV& DataProvider::getDataSlice(int startCase, int endCase) {
+    const int cases = getNumCases();
+    endCase = std::min(endCase, cases);
+    const int n = endCase - startCase;
+    if (n <= 0) throw std::runtime_error("empty data slice");
+    _miniV.clear();
+    for (size_t i = 0; i < _data.size(); i++) {
+        DevMat& src = *_data[i];
+        DevMat& dst = *_mini[i];
+        dst.resize(src.rows(), n);
+        // column range of a row-major matrix -> dense (rows, n)
+        RT_HIP(hipMemcpy2DAsync(dst.data(), (size_t)n * sizeof(float), src.data() + startCase, (size_t)cases * sizeof(float), (size_t)n * sizeof(float),
+                                src.rows(), hipMemcpyDeviceToDevice, computeStream()));
+        _miniV.push_back(&dst);
+    }
+    return _miniV;
+}
+
+// ==========================================================================================
+// GradComm: RCCL through dlopen, so the module also loads on machines without RCCL and shares
+// whichever librccl the process already has (PyTorch bundles one with the same soname).
+// ==========================================================================================
+namespace {
+struct NcclUniqueId { char internal[128]; };
+typedef int (*fnGetUniqueId)(NcclUniqueId*);
+typedef int (*fnCommInitRank)(void**, int, NcclUniqueId, int);
+typedef int (*fnAllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fnCommDestroy)(void*);
+typedef const char* (*fnGetErrorString)(int);
+struct Rccl {
+    void* h = nullptr;
+    fnGetUniqueId getUniqueId = nullptr;
+    fnCommInitRank commInitRank = nullptr;
+    fnAllReduce allReduce = nullptr;
+    fnCommDestroy commDestroy = nullptr;
+    fnGetErrorString getErrorString = nullptr;
+};
+Rccl& rccl() {
+    static Rccl r;
+    if (r.h) return r;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (r.h) break;
+    }
+    if (!r.h) throw std::runtime_error(std::string("unable to load librccl: ") + dlerror());
+    r.getUniqueId = (fnGetUniqueId)dlsym(r.h, "ncclGetUniqueId");
+    r.commInitRank = (fnCommInitRank)dlsym(r.h, "ncclCommInitRank");
+    r.allReduce = (fnAllReduce)dlsym(r.h, "ncclAllReduce");
+    r.commDestroy = (fnCommDestroy)dlsym(r.h, "ncclCommDestroy");
+    r.getErrorString = (fnGetErrorString)dlsym(r.h, "ncclGetErrorString");
+    if (!r.getUniqueId || !r.commInitRank || !r.allReduce || !r.commDestroy) throw std::runtime_error("librccl lacks an expected symbol");
+    return r;
+}
+void nccl_check(int rc, const char* what) {
+    if (rc != 0) throw std::runtime_error(fmt("%s failed: %s", what, rccl().getErrorString ? rccl().getErrorString(rc) : "?"));
+}
+const int kNcclFloat = 7, kNcclSum = 0;   // ncclFloat32, ncclSum (rccl.h)
+}  // namespace
+
+std::string GradComm::newUniqueId() {
+    NcclUniqueId id;
+    nccl_check(rccl().getUniqueId(&id), "ncclGetUniqueId");
+    return std::string(id.internal, sizeof(id.internal));
+}
+
+void GradComm::init(int rank, int world, const std::string& uniqueId, int device) {
+    if (_comm) throw std::runtime_error("data-parallel communicator already initialised");
+    if (uniqueId.size() != sizeof(NcclUniqueId)) throw std::runtime_error("RCCL unique id must be 128 bytes");
+    NcclUniqueId id;
+    memcpy(id.internal, uniqueId.data(), sizeof(id.internal));
+    RT_HIP(hipSetDevice(device));
+    nccl_check(rccl().commInitRank(&_comm, world, id, rank), "ncclCommInitRank");
+    RT_HIP(hipStreamCreateWithFlags(&_stream, hipStreamNonBlocking));
+    RT_HIP(hipEventCreateWithFlags(&_ready, hipEventDisableTiming));
+    _rank = rank;
+    _world = world;
+}
+
+GradComm::~GradComm() {
+    // the communicator lives for the life of the process, like the model (pyconvnet.cu:47)
+}
+
+void GradComm::allReduceAsync(float* p, size_t n, hipStream_t producer) {
+    if (!_comm || n == 0) return;
+    // the side stream picks up after everything the compute stream has queued so far
+    RT_HIP(hipEventRecord(_ready, producer));
+    RT_HIP(hipStreamWaitEvent(_stream, _ready, 0));
+    nccl_check(rccl().allReduce(p, p, n, kNcclFloat, kNcclSum, _comm, _stream), "ncclAllReduce");
+    _pending = true;
+}
+
+void GradComm::waitAll(hipStream_t consumer) {
+    if (!_pending) return;
+    if (_events.empty()) {
+        hipEvent_t e;
+        RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        _events.push_back(e);
+    }
+    RT_HIP(hipEventRecord(_events[0], _stream));
+    RT_HIP(hipStreamWaitEvent(consumer, _events[0], 0));
+    _pending = false;
+}
+
+// ==========================================================================================
+// ConvNet                                                                 (convnet.cu:46-257)
+// ==========================================================================================
+ConvNet::ConvNet(PyObject* layerParams, int minibatchSize, int deviceID) : _deviceID(deviceID) {
+    _seed = (unsigned long long)time(nullptr);
+    const int numLayers = (int)PyList_GET_SIZE(layerParams);
+    for (int i = 0; i < numLayers; i++) {
+        PyObject* paramsDict = PyList_GET_ITEM(layerParams, i);
+        if (!PyDict_Check(paramsDict)) throw std::runtime_error(fmt("layer %d is not a dictionary", i));
+        const std::string layerType = pyDictGetString(paramsDict, "type");
+        Layer* l = initLayer(layerType, paramsDict);
+        intv* inputLayers = pyDictGetIntV(paramsDict, "inputs");
+        if (inputLayers) {
+            for (int idx : *inputLayers) {
+                if (idx < 0 || idx >= i) throw std::runtime_error(fmt("layer '%s': input index %d out of range", l->getName().c_str(), idx));
+                l->addPrev(&getLayer(idx));
+            }
+        }
+        delete inputLayers;
+    }
+    for (Layer* l : _layers)
+        for (Layer* p : l->getPrev()) p->addNext(l);
+    for (Layer* l : _layers) l->postInit();
+    _dp = new DataProvider(minibatchSize);
+}
+
+ConvNet::~ConvNet() {}
+
+Layer* ConvNet::initLayer(const std::string& layerType, PyObject* paramsDict) {
+    Layer* l;
+    if (layerType == "fc") l = new FCLayer(this, paramsDict);
+    else if (layerType == "conv") l = new ConvLayer(this, paramsDict);
+    else if (layerType == "local") l = new LocalUnsharedLayer(this, paramsDict);
+    else if (layerType == "pool") l = &PoolLayer::makePoolLayer(this, paramsDict);
+    else if (layerType == "rnorm") l = new ResponseNormLayer(this, paramsDict);
+    else if (layerType == "cmrnorm") l = new CrossMapResponseNormLayer(this, paramsDict);
+    else if (layerType == "cnorm") l = new ContrastNormLayer(this, paramsDict);
+    else if (layerType == "softmax") l = new SoftmaxLayer(this, paramsDict);
+    else if (layerType == "eltsum") l = new EltwiseSumLayer(this, paramsDict);
+    else if (layerType == "neuron") l = new NeuronLayer(this, paramsDict);
+    else if (layerType == "data") {
+        DataLayer* d = new DataLayer(this, paramsDict);
+        _dataLayers.push_back(d);
+        l = d;
+    } else if (layerType.compare(0, 5, "cost.") == 0) {
+        CostLayer* c = &CostLayer::makeCostLayer(this, layerType, paramsDict);
+        _costs.push_back(c);
+        l = c;
+    } else if (pluginLayers().count(layerType)) {
+        l = pluginLayers()[layerType](this, paramsDict);
+    } else {
+        throw std::runtime_error("Unknown layer type " + layerType +
+                                 " (eltmax, nailbed, blur, resize, rgb2yuv, rgb2lab are outside this runtime's scope; plugin types need Plugins/*.so)");
+    }
+    _layers.push_back(l);
+    return l;
+}
+
+void ConvNet::start() { _thread = std::thread([this] { run(); }); _thread.detach(); }
+
+void ConvNet::initDevice() {
+    int dev = _deviceID;
+    if (dev < 0) dev = 0;   // "pick for me": devices of one node are identical
+    RT_HIP(hipSetDevice(dev));
+    _deviceID = dev;
+    char arch[64] = "";
+    int cus = 0;
+    RT_MC(mc_device_info(arch, sizeof(arch), &cus));
+    if (strncmp(arch, "gfx950", 6) != 0)
+        throw std::runtime_error(fmt("device %d is '%s'; the kernels of libmckernels.so are built for gfx950 (MI355X) only", dev, arch));
+    RT_HIP(hipStreamCreateWithFlags(&_stream, hipStreamNonBlocking));
+    setComputeStream(_stream);
+    copyToGPU();
+}
+
+void ConvNet::run() {
+    bool ready = false;
+    std::string initError;
+    try {
+        initDevice();
+        ready = true;
+    } catch (std::exception& e) {
+        initError = e.what();
+        std::cout << "Error initialising the device: " << initError << std::endl;
+    }
+    while (true) {
+        Worker* worker = _workerQueue.dequeue();
+        try {
+            if (!ready) throw std::runtime_error("device initialisation failed: " + initError);
+            worker->run();
+        } catch (std::exception& e) {
+            _resultQueue.enqueue(new WorkResult(WorkResult::ERROR, nullptr, e.what()));
+        }
+        // the item is deleted by the Python thread, which owns the references it holds
+    }
+}
+
+void ConvNet::copyToCPU() {
+    for (Layer* l : _layers) l->copyToCPU();
+}
+
+// Lays every owned tensor out in three arenas (weights, increments, gradients), in the order
+// back-propagation completes gradients (last layer first; biases before weights, as
+// WeightLayer::bpropCommon runs), each tensor aligned to 256 bytes.
+void ConvNet::copyToGPU() {
+    std::vector<Weights*> order;
+    for (auto it = _layers.rbegin(); it != _layers.rend(); ++it) {
+        WeightLayer* wl = dynamic_cast<WeightLayer*>(*it);
+        if (!wl) continue;
+        order.push_back(&wl->getBiases());
+        for (int i = 0; i < wl->getNumWeights(); i++)
+            if (wl->getWeights(i).isOwner()) order.push_back(&wl->getWeights(i));
+    }
+    size_t total = 0;
+    std::vector<size_t> offs;
+    for (Weights* w : order) {
+        offs.push_back(total);
+        total += (w->numel() + 63) / 64 * 64;
+    }
+    _arenaElems = total;
+    if (total) {
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&_arenaW), total * sizeof(float)));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&_arenaInc), total * sizeof(float)));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&_arenaGrad), total * sizeof(float)));
+        RT_HIP(hipMemset(_arenaW, 0, total * sizeof(float)));
+        RT_HIP(hipMemset(_arenaInc, 0, total * sizeof(float)));
+        RT_HIP(hipMemset(_arenaGrad, 0, total * sizeof(float)));
+    }
+    for (size_t i = 0; i < order.size(); i++) order[i]->bind(_arenaW + offs[i], _arenaInc + offs[i], _arenaGrad + offs[i], offs[i]);
+    _allWeights = order;
+    for (Layer* l : _layers) {
+        WeightLayer* wl = dynamic_cast<WeightLayer*>(l);
+        for (int i = 0; wl && i < wl->getNumWeights(); i++) _sharedWeights |= !wl->getWeights(i).isOwner();
+    }
+    for (Layer* l : _layers) l->copyToGPU();
+    RT_HIP(hipDeviceSynchronize());
+}
+
+void ConvNet::releaseHost() {
+    for (Layer* l : _layers) l->releaseHost();
+}
+
+float* ConvNet::workspace(size_t bytes) {
+    if (bytes > _workspaceBytes) {
+        if (_workspace) {
+            RT_HIP(hipStreamSynchronize(_stream));
+            RT_HIP(hipFree(_workspace));
+        }
+        _workspaceBytes = (bytes + (4u << 20)) / (4u << 20) * (4u << 20);
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&_workspace), _workspaceBytes));
+    }
+    return _workspace;
+}
+
+unsigned long long ConvNet::nextRandOffset(size_t n) {
+    const unsigned long long o = _randOffset;
+    _randOffset += n;
+    return o;
+}
+
+void ConvNet::reset() {
+    for (Layer* l : _layers) l->reset();
+}
+
+void ConvNet::fprop(PASS_TYPE passType) {
+    if (!_data) throw std::runtime_error("fprop without data");
+    reset();
+    for (DataLayer* d : _dataLayers) d->fprop(*_data, passType);
+}
+
+void ConvNet::fprop(DevMatV& data, PASS_TYPE passType) {
+    _data = &data;
+    fprop(passType);
+}
+
+void ConvNet::fprop(int miniIdx, PASS_TYPE passType) {
+    _data = &_dp->getMinibatch(miniIdx);
+    fprop(passType);
+}
+
+void ConvNet::bprop(PASS_TYPE passType) {
+    _bucketLo = _bucketHi = 0;
+    for (CostLayer* c : _costs) c->bprop(passType);
+    reset();
+    if (_comm.active() && passType == PASS_TRAIN) {
+        // whatever has not been sent yet goes now; the update then waits for the side stream
+        flushBuckets(true);
+        _comm.waitAll(_stream);
+    }
+}
+
+// Tensors become ready in (roughly) arena order.  Ready tensors are coalesced into buckets of
+// at least kBucketElems and reduced while the rest of back-propagation runs; anything out of
+// order simply waits for the final flush, which reduces the remainder of the arena.
+static const size_t kBucketElems = 256 * 1024;   // 1 MiB of fp32
+
+void ConvNet::gradientReady(Weights& w) {
+    if (!_comm.active() || _sharedWeights) return;
+    const size_t lo = w.arenaOffset(), hi = lo + (w.numel() + 63) / 64 * 64;
+    if (lo == _bucketHi) {
+        _bucketHi = hi;
+        if (_bucketHi - _bucketLo >= kBucketElems) flushBuckets(false);
+    }
+}
+
+void ConvNet::flushBuckets(bool force) {
+    if (force) _bucketHi = _arenaElems;
+    if (_bucketHi > _bucketLo) {
+        _comm.allReduceAsync(_arenaGrad + _bucketLo, _bucketHi - _bucketLo, _stream);
+        _bucketLo = _bucketHi;
+    }
+}
+
+void ConvNet::updateWeights() {
+    for (Layer* l : _layers) l->updateWeights();
+}
+
+void ConvNet::endMinibatchCosts(int numCases) {
+    _slotCases.push_back(numCases);
+    _slot++;
+}
+
+Cost* ConvNet::collectCosts() {
+    RT_HIP(hipStreamSynchronize(_stream));
+    int total = 0;
+    for (int n : _slotCases) total += n;
+    Cost* cost = new Cost(total);
+    for (CostLayer* c : _costs) {
+        const int nv = c->numCostValues();
+        std::vector<double> host((size_t)_slot * nv);
+        if (_slot && c->deviceSlots()) RT_HIP(hipMemcpy(host.data(), c->deviceSlots(), host.size() * sizeof(double), hipMemcpyDeviceToHost));
+        std::vector<double> zero(nv, 0.0);
+        cost->add(c->getName(), c->getCoeff(), zero.data(), nv);
+        for (int s = 0; s < _slot; s++) {
+            c->finishCost(&host[(size_t)s * nv], _slotCases[s]);
+            cost->add(c->getName(), c->getCoeff(), &host[(size_t)s * nv], nv);
+        }
+    }
+    return cost;
+}
+
+double ConvNet::getCostValue() {
+    RT_HIP(hipStreamSynchronize(_stream));
+    double val = 0;
+    const int numCases = _data ? (*_data)[0]->cols() : 0;
+    for (CostLayer* c : _costs) {
+        const int nv = c->numCostValues();
+        std::vector<double> host(nv, 0.0);
+        if (c->deviceSlots()) RT_HIP(hipMemcpy(host.data(), c->deviceSlots() + (size_t)_slot * nv, nv * sizeof(double), hipMemcpyDeviceToHost));
+        c->finishCost(host.data(), numCases);
+        val += c->getCoeff() * host[0];
+    }
+    return val;
+}
+
+// ------------------------------------------------------------------------------------------
+// Numerical gradient check                                               (convnet.cu:262-335)
+// ------------------------------------------------------------------------------------------
+static const float GC_REL_ERR_THRESH = 0.02f;   // Kernel/include/util.cuh:46
+
+int ConvNet::checkGradients() {
+    _numFailures = 0;
+    _numTests = 0;
+    beginBatchCosts();
+    fprop(0, PASS_GC);
+    _baseErr = getCostValue();
+    bprop(PASS_GC);
+    for (Layer* l : _layers) l->checkGradients();
+    std::cout << "------------------------" << std::endl;
+    if (_numFailures > 0) std::cout << _numFailures << "/" << _numTests << " TESTS FAILED" << std::endl;
+    else std::cout << "ALL " << _numTests << " TESTS PASSED" << std::endl;
+    return _numFailures;
+}
+
+bool ConvNet::checkGradient(const std::string& name, float eps, Weights& weights) {
+    const int rows = weights.getNumRows(), cols = weights.getNumCols();
+    const size_t n = weights.numel();
+    const int numCases = (*_data)[0]->cols();
+    std::vector<float> w(n), numGrad(n, 0.f), grad(n);
+    RT_HIP(hipStreamSynchronize(_stream));
+    RT_HIP(hipMemcpy(w.data(), weights.getW(), n * sizeof(float), hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(grad.data(), weights.getGrad(), n * sizeof(float), hipMemcpyDeviceToHost));   // before any re-fprop
+    for (int i = 0; i < rows; i++) {
+        for (int j = 0; j < cols; j++) {
+            const size_t d = weights.deviceIndex(i, j);
+            const float bumped = w[d] + eps;
+            RT_HIP(hipMemcpy(weights.getW() + d, &bumped, sizeof(float), hipMemcpyHostToDevice));
+            fprop(PASS_GC);
+            const double err = getCostValue();
+            numGrad[d] = (float)((err - _baseErr) / (numCases * eps));
+            if (std::isnan(numGrad[d]) || std::isinf(numGrad[d])) {
+                std::cout << "Numerical computation produced nan or inf when checking '" << name << "': " << numGrad[d] << std::endl;
+                std::cout << "Consider reducing the sizes of the weights or finite difference steps." << std::endl;
+                throw std::runtime_error("gradient check aborted");
+            }
+            RT_HIP(hipMemcpy(weights.getW() + d, &w[d], sizeof(float), hipMemcpyHostToDevice));
+        }
+    }
+    double analNorm = 0, numNorm = 0, diffNorm = 0;
+    for (size_t k = 0; k < n; k++) {
+        const double a = -(double)grad[k] / numCases;
+        analNorm += a * a;
+        numNorm += (double)numGrad[k] * numGrad[k];
+        diffNorm += (numGrad[k] - a) * (numGrad[k] - a);
+    }
+    analNorm = sqrt(analNorm); numNorm = sqrt(numNorm); diffNorm = sqrt(diffNorm);
+    const double relErr = diffNorm / analNorm;
+    const bool fail = !(relErr < GC_REL_ERR_THRESH);
+    std::cout << "========================" << std::endl;
+    printf("(%s) %s GRADIENT CHECK\n", fail ? "****FAIL****" : "PASS", name.c_str());
+    std::cout << "========================" << std::endl;
+    printf("Analytic norm: %e\n", analNorm);
+    printf("Numeric norm:  %e\n", numNorm);
+    printf("Relative error: %e\n", relErr);
+    fflush(stdout);
+    _numTests++;
+    _numFailures += fail;
+    return fail;
+}
+
+std::map<std::string, DevMat*> ConvNet::debugActs() {
+    std::map<std::string, DevMat*> m;
+    for (Layer* l : _layers) {
+        try { m[l->getName()] = &l->getActs(); } catch (...) {}
+    }
+    return m;
+}
+
+// ==========================================================================================
+// Work items                                                               (worker.cu:61-214)
+// ==========================================================================================
+DataWorker::~DataWorker() {
+    if (_data) {
+        for (HostMat* m : *_data) delete m;
+        delete _data;
+    }
+}
+
+void DataWorker::releaseHost() {
+    if (_data)
+        for (HostMat* m : *_data) m->release();
+}
+
+void TrainingWorker::run() {
+    DataProvider& dp = _convNet->getDataProvider();
+    dp.setData(*_data);
+    _convNet->beginBatchCosts();
+    for (int i = 0; i < dp.getNumMinibatches(); i++) {
+        _convNet->fprop(i, _test ? PASS_TEST : PASS_TRAIN);
+        _convNet->endMinibatchCosts(dp.getNumCasesInMinibatch(i));
+        if (!_test) {
+            _convNet->bprop(PASS_TRAIN);
+            _convNet->updateWeights();
+        }
+    }
+    Cost* cost = _convNet->collectCosts();   // synchronises the stream
+    dp.clearData();
+    _convNet->getResultQueue().enqueue(new WorkResult(WorkResult::BATCH_DONE, cost));
+}
+
+void ResidentWorker::run() {
+    DataProvider& dp = _convNet->getDataProvider();
+    const int nmb = dp.getNumMinibatches();
+    _convNet->beginBatchCosts();
+    for (int k = 0; k < _count; k++) {
+        const int i = (_first + k) % nmb;
+        _convNet->fprop(i, _test ? PASS_TEST : PASS_TRAIN);
+        _convNet->endMinibatchCosts(dp.getNumCasesInMinibatch(i));
+        if (!_test) {
+            _convNet->bprop(PASS_TRAIN);
+            _convNet->updateWeights();
+        }
+    }
+    _convNet->getResultQueue().enqueue(new WorkResult(WorkResult::BATCH_DONE, _convNet->collectCosts()));
+}
+
+void SyncWorker::run() {
+    _convNet->copyToCPU();
+    _convNet->getResultQueue().enqueue(new WorkResult(WorkResult::SYNC_DONE));
+}
+
+void GradCheckWorker::run() {
+    _convNet->getDataProvider().setData(*_data);
+    const int failures = _convNet->checkGradients();
+    WorkResult* r = new WorkResult(WorkResult::BATCH_DONE, new Cost(0));
+    r->intValue = failures;
+    _convNet->getResultQueue().enqueue(r);
+}
+
+void MultiviewTestWorker::run() {
+    DataProvider& dp = _convNet->getDataProvider();
+    dp.setData(*_data);
+    if (dp.getNumCases() % _numViews != 0) throw std::runtime_error("multiview test: cases not divisible by the number of views");
+    Layer& logregLayer = _convNet->getLayer(_logregIdx);
+    const int numCasesReal = dp.getNumCases() / _numViews;
+    const int mb = dp.getMinibatchSize();
+    const int numMiniReal = (numCasesReal + mb - 1) / mb;
+    _convNet->beginBatchCosts();
+    DevMat softmaxActs, labels;
+    for (int i = 0; i < numMiniReal; i++) {
+        int n = 0;
+        for (int v = 0; v < _numViews; v++) {
+            DevMatV& mini = dp.getDataSlice(v * numCasesReal + i * mb, std::min((v + 1) * numCasesReal, v * numCasesReal + (i + 1) * mb));
+            _convNet->fprop(mini, PASS_TEST);
+            DevMat& probs = logregLayer.getPrev()[1]->getActs();
+            n = probs.cols();
+            if (v == 0) {
+                softmaxActs.copyFrom(probs);
+                labels.copyFrom(logregLayer.getPrev()[0]->getActs());
+            } else {
+                RT_MC(mc_axpby(softmaxActs.data(), probs.data(), 1.f, 1.f, probs.numel(), ST()));
+            }
+        }
+        RT_MC(mc_scale(softmaxActs.data(), softmaxActs.data(), 1.f / _numViews, softmaxActs.numel(), ST()));
+        DevMatV logregInput;
+        logregInput.push_back(&labels);
+        logregInput.push_back(&softmaxActs);
+        logregLayer.fprop(logregInput, PASS_TEST);
+        _convNet->endMinibatchCosts(n);
+    }
+    Cost* cost = _convNet->collectCosts();
+    dp.clearData();
+    _convNet->getResultQueue().enqueue(new WorkResult(WorkResult::BATCH_DONE, cost));
+}
+
+void FeatureWorker::releaseHost() {
+    DataWorker::releaseHost();
+    if (_ftrs) {
+        _ftrs->release();
+        delete _ftrs;
+        _ftrs = nullptr;
+    }
+}
+
+void FeatureWorker::run() {
+    DataProvider& dp = _convNet->getDataProvider();
+    dp.setData(*_data);
+    Layer& ftrLayer = _convNet->getLayer(_layerIdx);
+    if (_ftrs->fortran() || _ftrs->rows() != dp.getNumCases()) throw std::runtime_error("feature matrix must be C-ordered (numCases, layerOutputs)");
+    _convNet->beginBatchCosts();
+    std::vector<float> host;
+    for (int i = 0; i < dp.getNumMinibatches(); i++) {
+        _convNet->fprop(i, PASS_TEST);
+        const int n = dp.getNumCasesInMinibatch(i);
+        _convNet->endMinibatchCosts(n);
+        DevMat& acts = ftrLayer.getActs();   // (outputs, n)
+        if (acts.rows() != _ftrs->cols()) throw std::runtime_error(fmt("feature matrix has %d columns, layer produces %d outputs", _ftrs->cols(), acts.rows()));
+        host.resize(acts.numel());
+        acts.copyToHost(host.data());
+        float* dst = _ftrs->data() + (size_t)i * dp.getMinibatchSize() * _ftrs->cols();
+        for (int c = 0; c < n; c++)
+            for (int f = 0; f < acts.rows(); f++) dst[(size_t)c * acts.rows() + f] = host[(size_t)f * n + c];
+    }
+    Cost* cost = _convNet->collectCosts();
+    dp.clearData();
+    _convNet->getResultQueue().enqueue(new WorkResult(WorkResult::BATCH_DONE, cost));
+}
+
+void CallWorker::run() {
+    _fn();
+    _convNet->getResultQueue().enqueue(new WorkResult(WorkResult::SYNC_DONE));
+}
+
+}  // namespace rt

@@ -1,0 +1,291 @@
+// convnet.h -- the model object, its worker thread and the work items the Python thread queues.
+// Follows Kernel/include/convnet/{convnet,worker,queue,thread,data}.cuh of the reference:
+// Python enqueues a Worker, one device thread dequeues and runs it, results come back through
+// a second queue (convnet.cu:149-158, queue.h:84-110).
+#pragma once
+#include <condition_variable>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <queue>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "layer.h"
+
+namespace rt {
+
+template <class T>
+class Queue {
+public:
+    void enqueue(T v) {
+        {
+            std::lock_guard<std::mutex> g(_m);
+            _q.push(v);
+        }
+        _cv.notify_one();
+    }
+    T dequeue() {
+        std::unique_lock<std::mutex> g(_m);
+        _cv.wait(g, [&] { return !_q.empty(); });
+        T v = _q.front();
+        _q.pop();
+        return v;
+    }
+
+private:
+    std::queue<T> _q;
+    std::mutex _m;
+    std::condition_variable _cv;
+};
+
+// name -> values, summed over the minibatches of a batch (Kernel/src/layers/cost.cu:38-107)
+typedef std::map<std::string, std::vector<double>> CostMap;
+class Cost {
+public:
+    explicit Cost(int numCases = 0) : _numCases(numCases) {}
+    void add(const std::string& name, float coeff, const double* vals, int n);
+    void addCases(int n) { _numCases += n; }
+    int getNumCases() const { return _numCases; }
+    CostMap& getCostMap() { return _costMap; }
+    double getValue() const;   // sum_k coeff_k * cost_k[0]
+private:
+    int _numCases;
+    CostMap _costMap;
+    std::map<std::string, float> _coeffs;
+};
+
+// Host batch -> device minibatches (Kernel/src/data/data.cu:47-121).  The whole batch is
+// uploaded once; a minibatch is a column range gathered into a dense (dims, n) staging matrix
+// (the kernels take dense (features, numCases) operands).
+class DataProvider {
+public:
+    explicit DataProvider(int minibatchSize) : _minibatchSize(minibatchSize) {}
+    ~DataProvider();
+    void setData(HostMatV& data);
+    void clearData() { _hData = nullptr; }
+    DevMatV& getMinibatch(int idx);
+    DevMatV& getDataSlice(int startCase, int endCase);
+    int getNumMinibatches() const;
+    int getMinibatchSize() const { return _minibatchSize; }
+    int getNumCases() const;
+    int getNumCasesInMinibatch(int idx) const;
+
+private:
+    int _minibatchSize;
+    HostMatV* _hData = nullptr;
+    std::vector<DevMat*> _data;   // whole batch on the device
+    std::vector<DevMat*> _mini;   // staging
+    DevMatV _miniV;
+};
+
+// Gradient all-reduce over RCCL (new; the reference is single-GPU).  The gradient arena is cut
+// into buckets in back-propagation order; a bucket is reduced on a side stream as soon as the
+// last layer contributing to it has finished its bpropCommon, overlapped with the rest of
+// backprop; the weight update waits for all buckets.
+class GradComm {
+public:
+    ~GradComm();
+    // uniqueId: the 128 bytes of ncclGetUniqueId() from rank 0.  Must be called on the worker thread.
+    void init(int rank, int world, const std::string& uniqueId, int device);
+    static std::string newUniqueId();
+    bool active() const { return _world > 1 || _forced; }
+    int world() const { return _world; }
+    int rank() const { return _rank; }
+    void allReduceAsync(float* p, size_t n, hipStream_t producer);   // sum, in place
+    void waitAll(hipStream_t consumer);
+    void forceSingleRank(bool f) { _forced = f; }   // exercise the RCCL path with world == 1 (tests)
+
+private:
+    void* _comm = nullptr;
+    hipStream_t _stream = nullptr;
+    std::vector<hipEvent_t> _events;
+    size_t _nextEvent = 0;
+    hipEvent_t _ready = nullptr;
+    int _rank = 0, _world = 1;
+    bool _forced = false, _pending = false;
+};
+
+class Worker;
+class WorkResult {
+public:
+    enum RESULTS { BATCH_DONE, SYNC_DONE, ERROR };
+    WorkResult(RESULTS t, Cost* c = nullptr, const std::string& msg = "") : type(t), cost(c), message(msg) {}
+    ~WorkResult() { delete cost; }
+    RESULTS type;
+    Cost* cost;
+    std::string message;
+    int intValue = 0;
+};
+
+class ConvNet {
+public:
+    ConvNet(PyObject* layerParams, int minibatchSize, int deviceID);
+    ~ConvNet();
+    void start();   // spawns the device thread (convnet.cu:149-158)
+
+    Queue<Worker*>& getWorkerQueue() { return _workerQueue; }
+    Queue<WorkResult*>& getResultQueue() { return _resultQueue; }
+    DataProvider& getDataProvider() { return *_dp; }
+    Layer& operator[](int idx) { return *_layers[idx]; }
+    Layer& getLayer(int idx) { return *_layers.at(idx); }
+    int getNumLayers() const { return (int)_layers.size(); }
+    GradComm& comm() { return _comm; }
+
+    void copyToCPU();
+    void copyToGPU();
+    void updateWeights();
+    void reset();
+    void fprop(PASS_TYPE passType);
+    void fprop(int miniIdx, PASS_TYPE passType);
+    void fprop(DevMatV& data, PASS_TYPE passType);
+    void bprop(PASS_TYPE passType);
+    // cost handling: slots on the device, read once per batch
+    int costSlotIndex() const { return _slot; }
+    void beginBatchCosts() { _slot = 0; _slotCases.clear(); }
+    void endMinibatchCosts(int numCases);
+    Cost* collectCosts();
+    double getCostValue();   // synchronous, last minibatch only (grad check)
+    int checkGradients();
+    bool checkGradient(const std::string& name, float eps, Weights& weights);
+
+    // plumbing for layers
+    void registerWeights(Weights* w) { _allWeights.push_back(w); }
+    void gradientReady(Weights& w);           // called from WeightLayer::bpropCommon
+    float* workspace(size_t bytes);
+    int gradScaleCases(int localCases) const { return localCases * _comm.world(); }
+    unsigned long long nextRandOffset(size_t n);
+    unsigned long long seed() const { return _seed; }
+    void setSeed(unsigned long long s) { _seed = s; _randOffset = 0; }
+    void releaseHost();
+    int deviceID() const { return _deviceID; }
+    // dropout mask injection for parity tests: name -> host mask consumed on the next fprop
+    std::map<std::string, std::vector<float>> injectedMasks;
+    std::map<std::string, DevMat*> debugActs();   // layer name -> output matrix
+
+private:
+    void run();
+    void initDevice();
+    Layer* initLayer(const std::string& layerType, PyObject* paramsDict);
+    void flushBuckets(bool force);
+
+    std::vector<Layer*> _layers;
+    std::vector<DataLayer*> _dataLayers;
+    std::vector<CostLayer*> _costs;
+    std::vector<Weights*> _allWeights;
+    DevMatV* _data = nullptr;
+    DataProvider* _dp;
+    int _deviceID;
+    std::thread _thread;
+    Queue<Worker*> _workerQueue;
+    Queue<WorkResult*> _resultQueue;
+    hipStream_t _stream = nullptr;
+    // arenas
+    float *_arenaW = nullptr, *_arenaInc = nullptr, *_arenaGrad = nullptr;
+    size_t _arenaElems = 0;
+    size_t _bucketLo = 0, _bucketHi = 0;   // [lo, hi) of gradient elements ready but not yet reduced
+    float* _workspace = nullptr;
+    size_t _workspaceBytes = 0;
+    GradComm _comm;
+    int _slot = 0;
+    std::vector<int> _slotCases;
+    double _baseErr = 0;
+    int _numTests = 0, _numFailures = 0;
+    bool _sharedWeights = false;   // some matrix has several contributing layers: reduce at the end only
+    unsigned long long _seed, _randOffset = 0;
+};
+
+// ------------------------------------------------------------------------------------------
+// Work items (Kernel/src/convnet/worker.cu:61-214)
+// ------------------------------------------------------------------------------------------
+class Worker {
+public:
+    explicit Worker(ConvNet& net) : _convNet(&net) {}
+    virtual ~Worker() {}
+    virtual void run() = 0;
+    // Python references held by the item; dropped by the Python thread after the result arrives.
+    virtual void releaseHost() {}
+
+protected:
+    ConvNet* _convNet;
+};
+
+class DataWorker : public Worker {
+public:
+    DataWorker(ConvNet& net, HostMatV* data) : Worker(net), _data(data) {}
+    ~DataWorker();
+    void releaseHost() override;
+
+protected:
+    HostMatV* _data;
+};
+
+class TrainingWorker : public DataWorker {
+public:
+    TrainingWorker(ConvNet& net, HostMatV* data, bool test) : DataWorker(net, data), _test(test) {}
+    void run() override;
+
+private:
+    bool _test;
+};
+
+// Re-runs minibatches of the batch that is already on the device (left there by the previous
+// startBatch): `count` steps starting at minibatch `first`, cycling.  Not in the reference; it
+// lets a benchmark time training steps with the inputs resident in HBM.
+class ResidentWorker : public Worker {
+public:
+    ResidentWorker(ConvNet& net, bool test, int first, int count) : Worker(net), _test(test), _first(first), _count(count) {}
+    void run() override;
+
+private:
+    bool _test;
+    int _first, _count;
+};
+
+class SyncWorker : public Worker {
+public:
+    explicit SyncWorker(ConvNet& net) : Worker(net) {}
+    void run() override;
+};
+
+class GradCheckWorker : public DataWorker {
+public:
+    GradCheckWorker(ConvNet& net, HostMatV* data) : DataWorker(net, data) {}
+    void run() override;
+};
+
+class MultiviewTestWorker : public DataWorker {
+public:
+    MultiviewTestWorker(ConvNet& net, HostMatV* data, int numViews, int logregIdx)
+        : DataWorker(net, data), _numViews(numViews), _logregIdx(logregIdx) {}
+    void run() override;
+
+private:
+    int _numViews, _logregIdx;
+};
+
+class FeatureWorker : public DataWorker {
+public:
+    FeatureWorker(ConvNet& net, HostMatV* data, HostMat* ftrs, int layerIdx)
+        : DataWorker(net, data), _ftrs(ftrs), _layerIdx(layerIdx) {}
+    void run() override;
+    void releaseHost() override;
+
+private:
+    HostMat* _ftrs;
+    int _layerIdx;
+};
+
+// Runs `fn` on the device thread and waits for it (used by the extra, non-reference entry
+// points: data-parallel set-up, test hooks).
+class CallWorker : public Worker {
+public:
+    CallWorker(ConvNet& net, std::function<void()> fn) : Worker(net), _fn(fn) {}
+    void run() override;
+
+private:
+    std::function<void()> _fn;
+};
+
+}  // namespace rt

@@ -1,0 +1,130 @@
+#include "devmat.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+
+namespace rt {
+
+std::string fmt(const char* f, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, f);
+    vsnprintf(buf, sizeof(buf), f, ap);
+    va_end(ap);
+    return std::string(buf);
+}
+
+static thread_local hipStream_t t_stream = nullptr;
+hipStream_t computeStream() { return t_stream; }
+void setComputeStream(hipStream_t s) { t_stream = s; }
+
+DeviceAllocator& DeviceAllocator::get() {
+    static DeviceAllocator a;
+    return a;
+}
+
+// Blocks are rounded up to 64 KiB below 8 MiB and to 2 MiB above, so the few distinct tensor
+// sizes of a net map onto few distinct block sizes and tail minibatches reuse the full-size blocks.
+static size_t round_capacity(size_t elems) {
+    const size_t bytes = elems * sizeof(float);
+    const size_t q = bytes < (8u << 20) ? (64u << 10) : (2u << 20);
+    return ((bytes + q - 1) / q * q) / sizeof(float);
+}
+
+float* DeviceAllocator::alloc(size_t elems, size_t* capacityOut) {
+    const size_t cap = round_capacity(elems ? elems : 1);
+    auto it = _free.lower_bound(cap);
+    // reuse a cached block unless it would waste more than half of itself
+    if (it != _free.end() && it->first <= 2 * cap) {
+        float* p = it->second;
+        *capacityOut = it->first;
+        _cached -= it->first * sizeof(float);
+        _inUse += it->first * sizeof(float);
+        _free.erase(it);
+        return p;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, cap * sizeof(float));
+    if (e != hipSuccess) {
+        trim();
+        e = hipMalloc(&p, cap * sizeof(float));
+    }
+    if (e != hipSuccess) throw std::runtime_error(fmt("hipMalloc of %zu bytes failed: %s", cap * sizeof(float), hipGetErrorString(e)));
+    *capacityOut = cap;
+    _inUse += cap * sizeof(float);
+    return static_cast<float*>(p);
+}
+
+void DeviceAllocator::release(float* p, size_t capacity) {
+    if (!p) return;
+    _free.insert({capacity, p});
+    _inUse -= capacity * sizeof(float);
+    _cached += capacity * sizeof(float);
+}
+
+void DeviceAllocator::trim() {
+    (void)hipDeviceSynchronize();
+    for (auto& kv : _free) (void)hipFree(kv.second);
+    _free.clear();
+    _cached = 0;
+}
+
+void DevMat::free() {
+    if (_own && _p) DeviceAllocator::get().release(_p, _cap);
+    _p = nullptr;
+    _cap = 0;
+    _rows = _cols = 0;
+    _own = true;
+}
+
+void DevMat::resize(int rows, int cols) {
+    if (rows < 0 || cols < 0) throw std::runtime_error(fmt("DevMat::resize(%d, %d)", rows, cols));
+    const size_t need = (size_t)rows * cols;
+    if (!_own) {
+        if (need > _cap) throw std::runtime_error("DevMat::resize: a view cannot grow");
+    } else if (need > _cap) {
+        // Blocks are recycled without synchronisation: every user of this memory is ordered on
+        // the one compute stream, so a later owner's kernels run after the earlier owner's.
+        if (_p) DeviceAllocator::get().release(_p, _cap);
+        _p = DeviceAllocator::get().alloc(need, &_cap);
+    }
+    _rows = rows;
+    _cols = cols;
+}
+
+void DevMat::reshape(int rows, int cols) {
+    if ((size_t)rows * cols != numel()) throw std::runtime_error(fmt("DevMat::reshape: %dx%d -> %dx%d changes the element count", _rows, _cols, rows, cols));
+    _rows = rows;
+    _cols = cols;
+}
+
+void DevMat::view(float* p, int rows, int cols) {
+    free();
+    _own = false;
+    _p = p;
+    _cap = (size_t)rows * cols;
+    _rows = rows;
+    _cols = cols;
+}
+
+void DevMat::copyFromHost(const float* h, int rows, int cols) {
+    resize(rows, cols);
+    if (numel()) RT_HIP(hipMemcpyAsync(_p, h, numel() * sizeof(float), hipMemcpyHostToDevice, computeStream()));
+}
+
+void DevMat::copyToHost(float* h) const {
+    if (!numel()) return;
+    RT_HIP(hipMemcpyAsync(h, _p, numel() * sizeof(float), hipMemcpyDeviceToHost, computeStream()));
+    RT_HIP(hipStreamSynchronize(computeStream()));
+}
+
+void DevMat::copyFrom(const DevMat& src) {
+    resize(src.rows(), src.cols());
+    if (numel()) RT_HIP(hipMemcpyAsync(_p, src.data(), numel() * sizeof(float), hipMemcpyDeviceToDevice, computeStream()));
+}
+
+void DevMat::zero() {
+    if (numel()) RT_HIP(hipMemsetAsync(_p, 0, numel() * sizeof(float), computeStream()));
+}
+
+}  // namespace rt

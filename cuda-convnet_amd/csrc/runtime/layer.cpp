@@ -1,0 +1,765 @@
+// layer.cpp -- layer graph semantics (reference: Kernel/src/layers/layer.cu, cited per block).
+#include "layer.h"
+
+#include <string.h>
+
+#include "convnet.h"
+
+namespace rt {
+
+static inline mcStream_t ST() { return reinterpret_cast<mcStream_t>(computeStream()); }
+
+// ==========================================================================================
+// Layer                                                                    (layer.cu:45-244)
+// ==========================================================================================
+Layer::Layer(ConvNet* convNet, PyObject* paramsDict) : _convNet(convNet) {
+    _name = pyDictGetString(paramsDict, "name");
+    _type = pyDictGetString(paramsDict, "type");
+    _gradConsumer = pyDictGetInt(paramsDict, "gradConsumer") != 0;
+    _actsTarget = pyDictGetInt(paramsDict, "actsTarget");
+    _actsGradTarget = pyDictGetInt(paramsDict, "actsGradTarget");
+    _conserveMem = pyDictGetInt(paramsDict, "conserveMem") != 0;
+    _numOutputs = pyDictHas(paramsDict, "outputs") ? pyDictGetInt(paramsDict, "outputs") : 0;
+    _outputs = _actsTarget < 0 ? &_ownOutputs : nullptr;
+    _actsGrad = _actsGradTarget < 0 ? &_ownActsGrad : nullptr;
+}
+
+void Layer::fpropNext(PASS_TYPE passType) {
+    for (Layer* l : _next) l->fprop(passType);
+}
+
+void Layer::truncBwdActs() {
+    if (_conserveMem && _actsGradTarget < 0) getActsGrad().free();
+    if (_conserveMem && _actsTarget < 0) getActs().free();
+}
+
+void Layer::fprop(PASS_TYPE passType) {
+    _rcvdFInputs += 1;
+    if (_rcvdFInputs == (int)_prev.size()) {
+        DevMatV v;
+        for (Layer* p : _prev) v.push_back(&p->getActs());
+        fprop(v, passType);
+    }
+}
+
+void Layer::fprop(DevMat& v, PASS_TYPE passType) {
+    DevMatV vl;
+    vl.push_back(&v);
+    fprop(vl, passType);
+}
+
+void Layer::fprop(DevMatV& v, PASS_TYPE passType) {
+    if (v.size() != _prev.size()) throw std::runtime_error(fmt("layer '%s': %zu inputs given, %zu expected", _name.c_str(), v.size(), _prev.size()));
+    _inputs = v;
+    _outputs = _actsTarget < 0 ? &_ownOutputs : _inputs[_actsTarget];
+    _rcvdFInputs = (int)_prev.size();
+    _numCases = v.empty() ? 0 : v[0]->cols();
+    for (size_t i = 0; i < v.size(); ++i)
+        if (v[i]->cols() != _numCases || (_prev[i]->getNumOutputs() > 0 && v[i]->rows() != _prev[i]->getNumOutputs()))
+            throw std::runtime_error(fmt("layer '%s': input %zu is %dx%d, expected %dx%d", _name.c_str(), i, v[i]->rows(), v[i]->cols(),
+                                         _prev[i]->getNumOutputs(), _numCases));
+    if (_actsTarget < 0 && _numOutputs > 0) _ownOutputs.resize(_numOutputs, _numCases);
+
+    // the input whose matrix this layer writes into goes first, the others accumulate
+    if (_actsTarget >= 0) fpropActs(_actsTarget, 0, passType);
+    for (int i = 0; i < (int)_prev.size(); i++)
+        if (i != _actsTarget) fpropActs(i, (_actsTarget >= 0 || i > 0) ? 1.f : 0.f, passType);
+    fpropNext(passType);
+}
+
+void Layer::bprop(PASS_TYPE passType) {
+    if (_rcvdBInputs == _numGradProducersNext) {
+        _rcvdBInputs++;   // guards against a second run
+        bprop(getActsGrad(), passType);
+    }
+}
+
+void Layer::bprop(DevMat& v, PASS_TYPE passType) {
+    bpropCommon(v, passType);
+    if (isGradProducer()) {
+        auto send = [&](int i) {
+            Layer* p = _prev[i];
+            DevMat& tgt = p->getActsGrad();
+            const bool accumulate = p->getRcvdBInputs() > 0;
+            if (!accumulate || tgt.rows() != p->getNumOutputs() || tgt.cols() != _numCases) {
+                if (accumulate) throw std::runtime_error(fmt("layer '%s': gradient of '%s' changed shape while accumulating", _name.c_str(), p->getName().c_str()));
+                tgt.resize(p->getNumOutputs(), _numCases);
+            }
+            bpropActs(v, i, accumulate ? 1.f : 0.f, passType);
+            p->incRcvdBInputs();
+        };
+        // first the inputs whose gradient matrix is certainly not this layer's own ...
+        for (int i = 0; i < (int)_prev.size(); i++)
+            if (_prev[i]->isGradConsumer() && _actsGradTarget != i) send(i);
+        // ... then the one it shares (the write may be in place)
+        if (_actsGradTarget >= 0 && _prev[_actsGradTarget]->isGradConsumer()) send(_actsGradTarget);
+    }
+    truncBwdActs();
+    if (isGradProducer())
+        for (Layer* p : _prev)
+            if (p->isGradConsumer()) p->bprop(passType);
+}
+
+void Layer::reset() {
+    _rcvdFInputs = 0;
+    _rcvdBInputs = 0;
+}
+
+void Layer::addNext(Layer* l) {
+    _next.push_back(l);
+    _numGradProducersNext += l->isGradProducer();
+}
+
+void Layer::postInit() {
+    _actsGrad = _actsGradTarget < 0 ? &_ownActsGrad : &_prev.at(_actsGradTarget)->getActsGrad();
+}
+
+bool Layer::isGradConsumer() {
+    if (!_foundGradConsumers) {
+        for (Layer* p : _prev) _gradConsumer |= p->isGradConsumer();
+        _foundGradConsumers = true;
+    }
+    return _gradConsumer;
+}
+
+DevMat& Layer::getActs() {
+    if (!_outputs) throw std::runtime_error(fmt("layer '%s' has no output yet", _name.c_str()));
+    return *_outputs;
+}
+
+DevMat& Layer::getActsGrad() {
+    if (!_actsGrad) throw std::runtime_error(fmt("layer '%s' has no gradient matrix", _name.c_str()));
+    return *_actsGrad;
+}
+
+// ==========================================================================================
+// Neurons                                               (neuron.cuh:65-462, neuron.cu:33-88)
+// ==========================================================================================
+void Neuron::activate(DevMat& inputs, DevMat& outputs, PASS_TYPE) {
+    _activated = true;
+    _inputs = &inputs;
+    _outputs = &outputs;
+    if (&inputs != &outputs) outputs.resize(inputs);
+    if (_mcType == MC_N_IDENT) {
+        if (&inputs != &outputs) outputs.copyFrom(inputs);
+        return;
+    }
+    RT_MC(mc_neuron_activate(_mcType, _a, _b, inputs.data(), outputs.data(), inputs.numel(), ST()));
+}
+
+void Neuron::computeInputGrad(DevMat& actsGrad, DevMat& target, bool add, PASS_TYPE) {
+    if (!_activated) throw std::runtime_error("neuron gradient requested before activation");
+    if (!add && &target != &actsGrad) target.resize(actsGrad);
+    if (_mcType == MC_N_IDENT) {
+        if (&target == &actsGrad) return;
+        if (!add) target.copyFrom(actsGrad);
+        else RT_MC(mc_axpby(target.data(), actsGrad.data(), 1.f, 1.f, target.numel(), ST()));
+        return;
+    }
+    const DevMat* ref = _usesInputs ? _inputs : _outputs;
+    RT_MC(mc_neuron_input_grad(_mcType, _a, _b, actsGrad.data(), ref->data(), target.data(), add ? 1 : 0, actsGrad.numel(), ST()));
+}
+
+class BuiltinNeuron : public Neuron {
+public:
+    BuiltinNeuron(int type, float a, float b, bool usesInputs) {
+        _mcType = type;
+        _a = a;
+        _b = b;
+        _usesInputs = usesInputs;
+    }
+    bool isRelu() const override { return _mcType == MC_N_RELU; }
+};
+
+Neuron& Neuron::makeNeuron(PyObject* neuronDict) {
+    if (!neuronDict) throw std::runtime_error("neuron layer without a 'neuron' entry");
+    const std::string type = pyDictGetString(neuronDict, "type");
+    PyObject* params = PyDict_GetItemString(neuronDict, "params");
+    auto P = [&](const char* k) { return pyDictGetFloat(params, k); };
+    if (type == "relu") return *new BuiltinNeuron(MC_N_RELU, 0, 0, false);
+    if (type == "softrelu") return *new BuiltinNeuron(MC_N_SOFTRELU, 0, 0, false);
+    if (type == "brelu") return *new BuiltinNeuron(MC_N_BRELU, P("a"), 0, false);
+    if (type == "abs") return *new BuiltinNeuron(MC_N_ABS, 0, 0, true);
+    if (type == "logistic") return *new BuiltinNeuron(MC_N_LOGISTIC, 0, 0, false);
+    if (type == "tanh") return *new BuiltinNeuron(MC_N_TANH, P("a"), P("b"), false);
+    if (type == "square") return *new BuiltinNeuron(MC_N_SQUARE, 0, 0, true);
+    if (type == "sqrt") return *new BuiltinNeuron(MC_N_SQRT, 0, 0, false);
+    if (type == "linear") return *new BuiltinNeuron(MC_N_LINEAR, P("a"), P("b"), false);
+    if (type == "ident") return *new Neuron();
+    auto it = pluginNeurons().find(type);
+    if (it != pluginNeurons().end()) return *it->second(params);
+    throw std::runtime_error("Unknown neuron type: " + type);
+}
+
+NeuronLayer::NeuronLayer(ConvNet* convNet, PyObject* paramsDict) : Layer(convNet, paramsDict) {
+    _neuron = &Neuron::makeNeuron(PyDict_GetItemString(paramsDict, "neuron"));
+}
+
+void NeuronLayer::fpropActs(int, float, PASS_TYPE passType) {
+    if (_fused) return;   // the producing contraction already applied relu in its epilogue, in place
+    _neuron->activate(*_inputs[0], getActs(), passType);
+}
+
+void NeuronLayer::bpropActs(DevMat& v, int, float scaleTargets, PASS_TYPE passType) {
+    if (_fused) {   // the fused path never ran activate(); the output IS the input matrix
+        DevMat& y = getActs();
+        DevMat& tgt = _prev[0]->getActsGrad();
+        RT_MC(mc_neuron_input_grad(MC_N_RELU, 0, 0, v.data(), y.data(), tgt.data(), scaleTargets > 0 ? 1 : 0, v.numel(), ST()));
+        return;
+    }
+    _neuron->computeInputGrad(v, _prev[0]->getActsGrad(), scaleTargets > 0, passType);
+}
+
+// ==========================================================================================
+// Weights                                                              (weights.cuh:41-219)
+// ==========================================================================================
+Weights::Weights(HostMat& hW, HostMat& hInc, float eps, float wc, float mom, bool deviceFortran)
+    : _hW(&hW), _hInc(&hInc), _eps(eps), _wc(wc), _mom(mom), _devFortran(deviceFortran) {
+    if (hW.rows() != hInc.rows() || hW.cols() != hInc.cols()) throw std::runtime_error("weights and weightsInc differ in shape");
+}
+
+Weights::Weights(Weights& src, float eps)
+    : _hW(nullptr), _hInc(nullptr), _src(&src), _eps(eps), _wc(0), _mom(src.getMom()) {
+    _hW = src._hW;
+    _hInc = src._hInc;
+}
+
+Weights::~Weights() {
+    if (!_src) {
+        delete _hW;
+        delete _hInc;
+    }
+}
+
+void Weights::releaseHost() {
+    if (!_src) {
+        _hW->release();
+        _hInc->release();
+    }
+}
+
+void Weights::bind(float* w, float* inc, float* grad, size_t offset) {
+    _w = w;
+    _inc = inc;
+    _grad = grad;
+    _offset = offset;
+}
+
+// host ndarray bytes -> device layout (row-major, or column-major when _devFortran)
+static void to_device_order(const HostMat& h, bool devFortran, std::vector<float>& buf) {
+    buf.resize(h.numel());
+    if (h.fortran() == devFortran) {
+        memcpy(buf.data(), h.data(), h.numel() * sizeof(float));
+        return;
+    }
+    std::vector<float> rm(h.numel());
+    h.toRowMajor(rm.data());
+    if (!devFortran) {
+        buf.swap(rm);
+        return;
+    }
+    for (int r = 0; r < h.rows(); ++r)
+        for (int c = 0; c < h.cols(); ++c) buf[(size_t)c * h.rows() + r] = rm[(size_t)r * h.cols() + c];
+}
+
+static void from_device_order(HostMat& h, bool devFortran, const std::vector<float>& buf) {
+    if (h.fortran() == devFortran) {
+        memcpy(h.data(), buf.data(), h.numel() * sizeof(float));
+        return;
+    }
+    if (!devFortran) {
+        h.fromRowMajor(buf.data());
+        return;
+    }
+    std::vector<float> rm(h.numel());
+    for (int r = 0; r < h.rows(); ++r)
+        for (int c = 0; c < h.cols(); ++c) rm[(size_t)r * h.cols() + c] = buf[(size_t)c * h.rows() + r];
+    h.fromRowMajor(rm.data());
+}
+
+void Weights::copyToGPU() {
+    if (_src) return;
+    if (!_w) throw std::runtime_error("Weights::copyToGPU before arena binding");
+    std::vector<float> buf;
+    to_device_order(*_hW, _devFortran, buf);
+    RT_HIP(hipMemcpy(_w, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice));
+    to_device_order(*_hInc, _devFortran, buf);
+    RT_HIP(hipMemcpy(_inc, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice));
+}
+
+void Weights::copyToCPU() {
+    if (_src) return;
+    std::vector<float> buf(numel());
+    RT_HIP(hipStreamSynchronize(computeStream()));
+    RT_HIP(hipMemcpy(buf.data(), _w, buf.size() * sizeof(float), hipMemcpyDeviceToHost));
+    from_device_order(*_hW, _devFortran, buf);
+    RT_HIP(hipMemcpy(buf.data(), _inc, buf.size() * sizeof(float), hipMemcpyDeviceToHost));
+    from_device_order(*_hInc, _devFortran, buf);
+}
+
+void Weights::update() {
+    // only the true owner updates, and only tensors that learn (weights.cuh:153)
+    if (_src == nullptr && _eps > 0) {
+        RT_MC(mc_weights_update(_w, _inc, _grad, numel(), _mom, _eps, _wc, ST()));
+        _numUpdates = 0;
+    }
+}
+
+// ==========================================================================================
+// WeightLayer                                                            (layer.cu:269-361)
+// ==========================================================================================
+WeightLayer::WeightLayer(ConvNet* convNet, PyObject* paramsDict, bool deviceFortran) : Layer(convNet, paramsDict) {
+    HostMatV* hWeights = pyDictGetMatrixV(paramsDict, "weights");
+    HostMatV* hWeightsInc = pyDictGetMatrixV(paramsDict, "weightsInc");
+    HostMat* hBiases = pyDictGetMatrix(paramsDict, "biases");
+    HostMat* hBiasesInc = pyDictGetMatrix(paramsDict, "biasesInc");
+    floatv* momW = pyDictGetFloatV(paramsDict, "momW");
+    floatv* epsW = pyDictGetFloatV(paramsDict, "epsW");
+    floatv* wc = pyDictGetFloatV(paramsDict, "wc");
+    const float momB = pyDictGetFloat(paramsDict, "momB"), epsB = pyDictGetFloat(paramsDict, "epsB");
+    intv* srcLayers = pyDictGetIntV(paramsDict, "weightSourceLayerIndices");
+    intv* srcMats = pyDictGetIntV(paramsDict, "weightSourceMatrixIndices");
+    if (!momW || !epsW || !wc || !srcLayers || !srcMats) throw std::runtime_error(fmt("layer '%s': missing weight hyper-parameters", _name.c_str()));
+    const size_t n = hWeights->size();
+    if (hWeightsInc->size() != n || momW->size() != n || epsW->size() != n || wc->size() != n || srcLayers->size() != n || srcMats->size() != n)
+        throw std::runtime_error(fmt("layer '%s': per-input weight lists differ in length", _name.c_str()));
+
+    for (size_t i = 0; i < n; i++) {
+        const int srcLayerIdx = srcLayers->at(i), matrixIdx = srcMats->at(i);
+        Weights* w;
+        if (srcLayerIdx == convNet->getNumLayers()) {          // another matrix of this very layer
+            w = new Weights(_weights[matrixIdx], epsW->at(i));
+        } else if (srcLayerIdx >= 0) {                           // a matrix of an earlier layer
+            WeightLayer* src = dynamic_cast<WeightLayer*>(&convNet->getLayer(srcLayerIdx));
+            if (!src) throw std::runtime_error(fmt("layer '%s': weight source layer %d has no weights", _name.c_str(), srcLayerIdx));
+            w = new Weights(src->getWeights(matrixIdx), epsW->at(i));
+        } else {
+            w = new Weights(*hWeights->at(i), *hWeightsInc->at(i), epsW->at(i), wc->at(i), momW->at(i), deviceFortran);
+            (*hWeights)[i] = nullptr;
+            (*hWeightsInc)[i] = nullptr;
+        }
+        _weights.addWeights(*w);
+        if (w->isOwner()) convNet->registerWeights(w);
+    }
+    // views of shared matrices were only needed for the shape checks Python already did
+    for (HostMatV* v : {hWeights, hWeightsInc})
+        for (HostMat* m : *v)
+            if (m) { m->release(); delete m; }
+    _biases = new Weights(*hBiases, *hBiasesInc, epsB, 0, momB, deviceFortran);
+    convNet->registerWeights(_biases);
+    delete hWeights; delete hWeightsInc; delete momW; delete epsW; delete wc; delete srcLayers; delete srcMats;
+}
+
+void WeightLayer::bpropCommon(DevMat& v, PASS_TYPE passType) {
+    if (_biases->getEps() > 0) {
+        bpropBiases(v, passType);
+        _convNet->gradientReady(*_biases);
+    }
+    for (int i = 0; i < _weights.getSize(); i++) {
+        if (_weights[i].getEps() > 0) {
+            bpropWeights(v, i, passType);
+            _weights[i].incNumUpdates();
+            _convNet->gradientReady(_weights[i]);
+        }
+    }
+}
+
+void WeightLayer::updateWeights() {
+    _weights.update();
+    _biases->update();
+}
+
+void WeightLayer::copyToCPU() {
+    _weights.copyToCPU();
+    _biases->copyToCPU();
+}
+
+void WeightLayer::copyToGPU() {
+    _weights.copyToGPU();
+    _biases->copyToGPU();
+}
+
+void WeightLayer::releaseHost() {
+    for (int i = 0; i < _weights.getSize(); i++) _weights[i].releaseHost();
+    _biases->releaseHost();
+}
+
+void WeightLayer::checkGradients() {
+    for (int i = 0; i < _weights.getSize(); i++) _convNet->checkGradient(_name + " weights[" + std::to_string(i) + "]", _wStep, _weights[i]);
+    _convNet->checkGradient(_name + " biases", _bStep, *_biases);
+}
+
+NeuronLayer* WeightLayer::fusableRelu() {
+    if (_prev.size() != 1 || _next.size() != 1) return nullptr;
+    NeuronLayer* nl = dynamic_cast<NeuronLayer*>(_next[0]);
+    if (!nl || !nl->inPlace() || !nl->getNeuron().isRelu()) return nullptr;
+    return nl;
+}
+
+float* WeightLayer::workspace(size_t bytes) { return _convNet->workspace(bytes); }
+
+// ==========================================================================================
+// FCLayer                                                                (layer.cu:368-409)
+// Device weights are (outputs, inputs) row-major = the Fortran-ordered (inputs, outputs) ndarray.
+// acts(out, N) = W(out, in) * x(in, N) + b
+// ==========================================================================================
+FCLayer::FCLayer(ConvNet* convNet, PyObject* paramsDict) : WeightLayer(convNet, paramsDict, true) {
+    _wStep = 0.1f;
+    _bStep = 0.01f;
+}
+
+void FCLayer::fpropActs(int inpIdx, float scaleTargets, PASS_TYPE) {
+    const int N = numCases(), in = _inputs[inpIdx]->rows(), out = _numOutputs;
+    NeuronLayer* relu = fusableRelu();
+    if (relu) relu->setFusedIntoProducer(true);
+    const size_t wsb = mc_gemm_workspace_bytes(out, N, in);
+    RT_MC(mc_gemm(_weights[inpIdx].getW(), _inputs[inpIdx]->data(), getActs().data(), out, N, in, 0, 0, in, N, N, scaleTargets, 1.f,
+                  scaleTargets == 0 ? _biases->getW() : nullptr, relu ? MC_NEURON_RELU : MC_NEURON_NONE, wsb ? workspace(wsb) : nullptr, wsb, ST()));
+}
+
+void FCLayer::bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE) {
+    const int N = numCases(), in = _prev[inpIdx]->getNumOutputs(), out = _numOutputs;
+    const size_t wsb = mc_gemm_workspace_bytes(in, N, out);
+    RT_MC(mc_gemm(_weights[inpIdx].getW(), v.data(), _prev[inpIdx]->getActsGrad().data(), in, N, out, 1, 0, in, N, N, scaleTargets, 1.f, nullptr,
+                  MC_NEURON_NONE, wsb ? workspace(wsb) : nullptr, wsb, ST()));
+}
+
+void FCLayer::bpropBiases(DevMat& v, PASS_TYPE passType) {
+    const float scale = passType == PASS_GC ? 1.f : _biases->getEps() / _convNet->gradScaleCases(numCases());
+    RT_MC(mc_sum_rows(v.data(), _biases->getGrad(), _numOutputs, numCases(), 0.f, scale, ST()));
+}
+
+void FCLayer::bpropWeights(DevMat& v, int inpIdx, PASS_TYPE passType) {
+    const int N = numCases(), in = _prev[inpIdx]->getNumOutputs(), out = _numOutputs;
+    const float scale = passType == PASS_GC ? 1.f : _weights[inpIdx].getEps() / _convNet->gradScaleCases(N);
+    const float scaleTargets = _weights[inpIdx].getNumUpdates() > 0 ? 1.f : 0.f;
+    const size_t wsb = mc_gemm_workspace_bytes(out, in, N);
+    // dW(out, in) = g(out, N) * x(in, N)^T
+    RT_MC(mc_gemm(v.data(), _prev[inpIdx]->getActs().data(), _weights[inpIdx].getGrad(), out, in, N, 0, 1, N, N, in, scaleTargets, scale, nullptr,
+                  MC_NEURON_NONE, wsb ? workspace(wsb) : nullptr, wsb, ST()));
+}
+
+// ==========================================================================================
+// LocalLayer / ConvLayer / LocalUnsharedLayer                             (layer.cu:416-602)
+// ==========================================================================================
+LocalLayer::LocalLayer(ConvNet* convNet, PyObject* paramsDict) : WeightLayer(convNet, paramsDict, false) {
+    _padding = pyDictGetIntV(paramsDict, "padding");
+    _stride = pyDictGetIntV(paramsDict, "stride");
+    _filterSize = pyDictGetIntV(paramsDict, "filterSize");
+    _channels = pyDictGetIntV(paramsDict, "channels");
+    _imgSize = pyDictGetIntV(paramsDict, "imgSize");
+    _groups = pyDictGetIntV(paramsDict, "groups");
+    _filterChannels = pyDictGetIntV(paramsDict, "filterChannels");
+    _randSparse = pyDictGetIntV(paramsDict, "randSparse");
+    _overSample = pyDictGetIntV(paramsDict, "overSample");
+    _filterPixels = pyDictGetIntV(paramsDict, "filterPixels");
+    _imgPixels = pyDictGetIntV(paramsDict, "imgPixels");
+    _numFilters = pyDictGetInt(paramsDict, "filters");
+    _modulesX = pyDictGetInt(paramsDict, "modulesX");
+    _modules = pyDictGetInt(paramsDict, "modules");
+    for (int rs : *_randSparse)
+        if (rs) throw std::runtime_error(fmt("layer '%s': randSparse connectivity is not supported by this runtime", _name.c_str()));
+}
+
+LocalLayer::~LocalLayer() {
+    for (intv* v : {_padding, _stride, _filterSize, _channels, _imgSize, _groups, _filterChannels, _randSparse, _overSample, _filterPixels, _imgPixels}) delete v;
+}
+
+#define CONV_GEOM(i) numCases(), _channels->at(i), _imgSize->at(i), _imgSize->at(i), _numFilters, _filterSize->at(i), _padding->at(i), _stride->at(i), _modulesX, _modulesX, _groups->at(i)
+
+ConvLayer::ConvLayer(ConvNet* convNet, PyObject* paramsDict) : LocalLayer(convNet, paramsDict) {
+    _partialSum = pyDictGetInt(paramsDict, "partialSum");
+    _sharedBiases = pyDictGetInt(paramsDict, "sharedBiases") != 0;
+}
+
+void ConvLayer::fpropActs(int i, float scaleTargets, PASS_TYPE) {
+    // bias (+ an in-place relu consumer) ride in the contraction's epilogue when the biases are
+    // shared per filter: the same values as convFilterActs + reshape/addVector (layer.cu:476-487)
+    const bool first = scaleTargets == 0;
+    NeuronLayer* relu = _sharedBiases ? fusableRelu() : nullptr;
+    if (relu) relu->setFusedIntoProducer(true);
+    RT_MC(mc_conv_filter_acts_fused(_inputs[i]->data(), _weights[i].getW(), getActs().data(), (first && _sharedBiases) ? _biases->getW() : nullptr,
+                                    relu ? MC_NEURON_RELU : MC_NEURON_NONE, CONV_GEOM(i), scaleTargets, 1.f, ST()));
+    if (first && !_sharedBiases) RT_MC(mc_add_row_vector(getActs().data(), _biases->getW(), _numFilters * _modules, numCases(), 1.f, ST()));
+}
+
+void ConvLayer::bpropBiases(DevMat& v, PASS_TYPE passType) {
+    const float scale = passType == PASS_GC ? 1.f : _biases->getEps() / _convNet->gradScaleCases(numCases());
+    if (_sharedBiases) RT_MC(mc_sum_rows(v.data(), _biases->getGrad(), _numFilters, _modules * numCases(), 0.f, scale, ST()));
+    else RT_MC(mc_sum_rows(v.data(), _biases->getGrad(), _numFilters * _modules, numCases(), 0.f, scale, ST()));
+}
+
+void ConvLayer::bpropWeights(DevMat& v, int i, PASS_TYPE passType) {
+    // The reference sums `partialSum` modules per chunk into a temporary and then reduces the
+    // chunks (layer.cu:503-523).  Same structure; the chunking is chosen for this device rather
+    // than read from the layer file (the sum is the same, only its association differs).
+    const float scale = passType == PASS_GC ? 1.f : _weights[i].getEps() / _convNet->gradScaleCases(numCases());
+    const float scaleTargets = _weights[i].getNumUpdates() > 0 ? 1.f : 0.f;
+    const int ps = mc_conv_weight_acts_pick_partial_sum(numCases(), _channels->at(i), _numFilters, _filterSize->at(i), _modules, _groups->at(i));
+    const int chunks = ps > 0 ? _modules / ps : 1;
+    const size_t welems = (size_t)_filterChannels->at(i) * _filterPixels->at(i) * _numFilters;
+    if (chunks <= 1) {
+        RT_MC(mc_conv_weight_acts(_prev[i]->getActs().data(), v.data(), _weights[i].getGrad(), CONV_GEOM(i), 0, scaleTargets, scale, ST()));
+        return;
+    }
+    float* tmp = workspace(welems * chunks * sizeof(float));
+    RT_MC(mc_conv_weight_acts(_prev[i]->getActs().data(), v.data(), tmp, CONV_GEOM(i), ps, 0.f, 1.f, ST()));
+    RT_MC(mc_sum_cols(tmp, _weights[i].getGrad(), chunks, (int)welems, scaleTargets, scale, ST()));
+}
+
+void ConvLayer::bpropActs(DevMat& v, int i, float scaleTargets, PASS_TYPE) {
+    RT_MC(mc_conv_img_acts(v.data(), _weights[i].getW(), _prev[i]->getActsGrad().data(), CONV_GEOM(i), scaleTargets, 1.f, ST()));
+}
+
+LocalUnsharedLayer::LocalUnsharedLayer(ConvNet* convNet, PyObject* paramsDict) : LocalLayer(convNet, paramsDict) {}
+
+void LocalUnsharedLayer::fpropActs(int i, float scaleTargets, PASS_TYPE) {
+    RT_MC(mc_local_filter_acts(_inputs[i]->data(), _weights[i].getW(), getActs().data(), CONV_GEOM(i), scaleTargets, 1.f, ST()));
+    if (scaleTargets == 0) RT_MC(mc_add_row_vector(getActs().data(), _biases->getW(), _numFilters * _modules, numCases(), 1.f, ST()));
+}
+
+void LocalUnsharedLayer::bpropBiases(DevMat& v, PASS_TYPE passType) {
+    const float scale = passType == PASS_GC ? 1.f : _biases->getEps() / _convNet->gradScaleCases(numCases());
+    RT_MC(mc_sum_rows(v.data(), _biases->getGrad(), _numFilters * _modules, numCases(), 0.f, scale, ST()));
+}
+
+void LocalUnsharedLayer::bpropWeights(DevMat& v, int i, PASS_TYPE passType) {
+    const float scale = passType == PASS_GC ? 1.f : _weights[i].getEps() / _convNet->gradScaleCases(numCases());
+    const float scaleTargets = _weights[i].getNumUpdates() > 0 ? 1.f : 0.f;
+    RT_MC(mc_local_weight_acts(_prev[i]->getActs().data(), v.data(), _weights[i].getGrad(), CONV_GEOM(i), scaleTargets, scale, ST()));
+}
+
+void LocalUnsharedLayer::bpropActs(DevMat& v, int i, float scaleTargets, PASS_TYPE) {
+    RT_MC(mc_local_img_acts(v.data(), _weights[i].getW(), _prev[i]->getActsGrad().data(), CONV_GEOM(i), scaleTargets, 1.f, ST()));
+}
+
+// ==========================================================================================
+// Softmax / eltsum / data                                                 (layer.cu:609-705)
+// ==========================================================================================
+void SoftmaxLayer::fpropActs(int, float, PASS_TYPE) {
+    RT_MC(mc_softmax(_inputs[0]->data(), getActs().data(), numCases(), _numOutputs, ST()));
+}
+
+void SoftmaxLayer::bpropActs(DevMat& v, int, float scaleTargets, PASS_TYPE) {
+    // directly under a logreg cost the fused gradient coeff*(1[label] - p) is used (layer.cu:626-631)
+    const bool doLogregGrad = _next.size() == 1 && _next[0]->getType() == "cost.logreg";
+    DevMat& tgt = _prev[0]->getActsGrad();
+    if (doLogregGrad) {
+        DevMat& labels = _next[0]->getPrev()[0]->getActs();
+        const float coeff = dynamic_cast<CostLayer*>(_next[0])->getCoeff();
+        RT_MC(mc_compute_logreg_softmax_grad(labels.data(), getActs().data(), tgt.data(), scaleTargets == 1, coeff, numCases(), _numOutputs, ST()));
+    } else {
+        RT_MC(mc_compute_softmax_grad(getActs().data(), v.data(), tgt.data(), scaleTargets == 1, numCases(), _numOutputs, ST()));
+    }
+}
+
+EltwiseSumLayer::EltwiseSumLayer(ConvNet* convNet, PyObject* paramsDict) : Layer(convNet, paramsDict) {
+    _coeffs = pyDictGetFloatV(paramsDict, "coeffs");
+    if (!_coeffs) throw std::runtime_error("eltsum layer without coeffs");
+}
+
+void EltwiseSumLayer::fpropActs(int i, float scaleTargets, PASS_TYPE) {
+    if (scaleTargets == 0) RT_MC(mc_scale(getActs().data(), _inputs[i]->data(), _coeffs->at(i), getActs().numel(), ST()));
+    else RT_MC(mc_axpby(getActs().data(), _inputs[i]->data(), 1.f, _coeffs->at(i), getActs().numel(), ST()));
+}
+
+void EltwiseSumLayer::bpropActs(DevMat& v, int i, float scaleTargets, PASS_TYPE) {
+    DevMat& tgt = _prev[i]->getActsGrad();
+    if (scaleTargets == 0) RT_MC(mc_scale(tgt.data(), v.data(), _coeffs->at(i), v.numel(), ST()));
+    else RT_MC(mc_axpby(tgt.data(), v.data(), scaleTargets, _coeffs->at(i), v.numel(), ST()));
+}
+
+DataLayer::DataLayer(ConvNet* convNet, PyObject* paramsDict) : Layer(convNet, paramsDict) {
+    _dataIdx = pyDictGetInt(paramsDict, "dataIdx");
+}
+
+void DataLayer::fprop(PASS_TYPE) { throw std::runtime_error("No data given!"); }
+
+void DataLayer::fprop(DevMatV& data, PASS_TYPE passType) {
+    if (_dataIdx < 0 || _dataIdx >= (int)data.size()) throw std::runtime_error(fmt("data layer '%s': dataIdx %d but %zu matrices given", _name.c_str(), _dataIdx, data.size()));
+    _outputs = data[_dataIdx];
+    if (_numOutputs > 0 && _outputs->rows() != _numOutputs)
+        throw std::runtime_error(fmt("data layer '%s': matrix has %d rows, layer expects %d", _name.c_str(), _outputs->rows(), _numOutputs));
+    _numCases = _outputs->cols();
+    fpropNext(passType);
+}
+
+// ==========================================================================================
+// Pooling                                                                  (layer.cu:712-763)
+// ==========================================================================================
+PoolLayer::PoolLayer(ConvNet* convNet, PyObject* paramsDict) : Layer(convNet, paramsDict) {
+    _channels = pyDictGetInt(paramsDict, "channels");
+    _sizeX = pyDictGetInt(paramsDict, "sizeX");
+    _start = pyDictGetInt(paramsDict, "start");
+    _stride = pyDictGetInt(paramsDict, "stride");
+    _outputsX = pyDictGetInt(paramsDict, "outputsX");
+    _imgSize = pyDictGetInt(paramsDict, "imgSize");
+    _pool = pyDictGetString(paramsDict, "pool");
+}
+
+PoolLayer& PoolLayer::makePoolLayer(ConvNet* convNet, PyObject* paramsDict) {
+    const std::string pool = pyDictGetString(paramsDict, "pool");
+    if (pool == "max") return *new MaxPoolLayer(convNet, paramsDict);
+    if (pool == "avg") return *new AvgPoolLayer(convNet, paramsDict);
+    throw std::runtime_error("Unknown pooling layer type " + pool);
+}
+
+void AvgPoolLayer::fpropActs(int, float, PASS_TYPE) {
+    RT_MC(mc_conv_local_pool(_inputs[0]->data(), getActs().data(), numCases(), _channels, _imgSize, _sizeX, _start, _stride, _outputsX, MC_POOL_AVG, ST()));
+}
+
+void AvgPoolLayer::bpropActs(DevMat& v, int, float scaleTargets, PASS_TYPE) {
+    RT_MC(mc_conv_local_avg_undo(v.data(), _prev[0]->getActsGrad().data(), numCases(), _channels, _imgSize, _sizeX, _start, _stride, _outputsX, scaleTargets, 1.f, ST()));
+}
+
+void MaxPoolLayer::fpropActs(int, float, PASS_TYPE) {
+    RT_MC(mc_conv_local_pool(_inputs[0]->data(), getActs().data(), numCases(), _channels, _imgSize, _sizeX, _start, _stride, _outputsX, MC_POOL_MAX, ST()));
+}
+
+void MaxPoolLayer::bpropActs(DevMat& v, int, float scaleTargets, PASS_TYPE) {
+    RT_MC(mc_conv_local_max_undo(_prev[0]->getActs().data(), v.data(), getActs().data(), _prev[0]->getActsGrad().data(), numCases(), _channels, _imgSize,
+                                 _sizeX, _start, _stride, _outputsX, scaleTargets, 1.f, ST()));
+}
+
+// ==========================================================================================
+// Normalisation                                                            (layer.cu:874-941)
+// ==========================================================================================
+ResponseNormLayer::ResponseNormLayer(ConvNet* convNet, PyObject* paramsDict) : Layer(convNet, paramsDict) {
+    _channels = pyDictGetInt(paramsDict, "channels");
+    _size = pyDictGetInt(paramsDict, "size");
+    _scale = pyDictGetFloat(paramsDict, "scale");
+    _pow = pyDictGetFloat(paramsDict, "pow");
+    _imgSize = pyDictGetInt(paramsDict, "imgSize");
+}
+
+void ResponseNormLayer::fpropActs(int, float, PASS_TYPE) {
+    _denoms.resize(getActs());
+    RT_MC(mc_conv_response_norm(_inputs[0]->data(), _denoms.data(), getActs().data(), numCases(), _channels, _imgSize, _size, _scale, _pow, ST()));
+}
+
+void ResponseNormLayer::bpropActs(DevMat& v, int, float scaleTargets, PASS_TYPE) {
+    RT_MC(mc_conv_response_norm_undo(v.data(), _denoms.data(), _prev[0]->getActs().data(), getActs().data(), _prev[0]->getActsGrad().data(), numCases(),
+                                     _channels, _imgSize, _size, _scale, _pow, scaleTargets, 1.f, ST()));
+}
+
+void ResponseNormLayer::truncBwdActs() {
+    Layer::truncBwdActs();
+    if (_conserveMem) _denoms.free();
+}
+
+CrossMapResponseNormLayer::CrossMapResponseNormLayer(ConvNet* convNet, PyObject* paramsDict) : ResponseNormLayer(convNet, paramsDict) {
+    _blocked = pyDictGetInt(paramsDict, "blocked") != 0;
+    _k = pyDictGetFloat(paramsDict, "k");
+}
+
+void CrossMapResponseNormLayer::fpropActs(int, float, PASS_TYPE) {
+    _denoms.resize(getActs());
+    RT_MC(mc_conv_response_norm_cross_map(_inputs[0]->data(), _denoms.data(), getActs().data(), numCases(), _channels, _imgSize, _size, _scale, _pow,
+                                          _blocked, _k, ST()));
+}
+
+void CrossMapResponseNormLayer::bpropActs(DevMat& v, int, float scaleTargets, PASS_TYPE) {
+    RT_MC(mc_conv_response_norm_cross_map_undo(v.data(), _denoms.data(), _prev[0]->getActs().data(), getActs().data(), _prev[0]->getActsGrad().data(),
+                                               numCases(), _channels, _imgSize, _size, _scale, _pow, _blocked, scaleTargets, 1.f, ST()));
+}
+
+void ContrastNormLayer::fpropActs(int, float, PASS_TYPE) {
+    DevMat& images = *_inputs[0];
+    _meanDiffs.resize(images);
+    _denoms.resize(getActs());
+    // meanDiffs = images - local mean (layer.cu:925-930)
+    RT_MC(mc_conv_local_pool(images.data(), _meanDiffs.data(), numCases(), _channels, _imgSize, _size, -_size / 2, 1, _imgSize, MC_POOL_AVG, ST()));
+    RT_MC(mc_axpby(_meanDiffs.data(), images.data(), -1.f, 1.f, images.numel(), ST()));
+    RT_MC(mc_conv_contrast_norm(images.data(), _meanDiffs.data(), _denoms.data(), getActs().data(), numCases(), _channels, _imgSize, _size, _scale, _pow, ST()));
+}
+
+void ContrastNormLayer::bpropActs(DevMat& v, int i, float scaleTargets, PASS_TYPE) {
+    RT_MC(mc_conv_response_norm_undo(v.data(), _denoms.data(), _meanDiffs.data(), getActs().data(), _prev[i]->getActsGrad().data(), numCases(), _channels,
+                                     _imgSize, _size, _scale, _pow, scaleTargets, 1.f, ST()));
+}
+
+void ContrastNormLayer::truncBwdActs() {
+    ResponseNormLayer::truncBwdActs();
+    if (_conserveMem) _meanDiffs.free();
+}
+
+// ==========================================================================================
+// Costs                                                                   (layer.cu:948-1036)
+// ==========================================================================================
+CostLayer::CostLayer(ConvNet* convNet, PyObject* paramsDict) : Layer(convNet, paramsDict) {
+    _coeff = pyDictGetFloat(paramsDict, "coeff");
+}
+
+CostLayer::~CostLayer() {
+    if (_slots) (void)hipFree(_slots);
+}
+
+double* CostLayer::costSlot() {
+    if (!_slots) {
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&_slots), sizeof(double) * MAX_SLOTS * numCostValues()));
+        // on the compute stream: a null-stream memset is not ordered against a non-blocking stream
+        RT_HIP(hipMemsetAsync(_slots, 0, sizeof(double) * MAX_SLOTS * numCostValues(), computeStream()));
+    }
+    const int s = _convNet->costSlotIndex();
+    if (s >= MAX_SLOTS) throw std::runtime_error(fmt("more than %d minibatches in one batch", MAX_SLOTS));
+    return _slots + (size_t)s * numCostValues();
+}
+
+void CostLayer::bprop(PASS_TYPE passType) {
+    if (_coeff != 0) Layer::bprop(passType);
+}
+
+CostLayer& CostLayer::makeCostLayer(ConvNet* convNet, const std::string& type, PyObject* paramsDict) {
+    if (type == "cost.logreg") return *new LogregCostLayer(convNet, paramsDict);
+    if (type == "cost.sum2") return *new SumOfSquaresCostLayer(convNet, paramsDict);
+    auto it = pluginLayers().find(type);
+    if (it != pluginLayers().end()) {
+        CostLayer* c = dynamic_cast<CostLayer*>(it->second(convNet, paramsDict));
+        if (!c) throw std::runtime_error("plugin layer '" + type + "' is not a cost layer");
+        return *c;
+    }
+    throw std::runtime_error("Unknown cost layer type " + type);
+}
+
+void LogregCostLayer::fpropActs(int inpIdx, float, PASS_TYPE) {
+    if (inpIdx != 0) return;   // both inputs are used together
+    DevMat& labels = *_inputs[0];
+    DevMat& probs = *_inputs[1];
+    const int N = labels.cols();
+    _ownOutputs.resize(1, N);       // log p(label) per case
+    _correctProbs.resize(1, N);
+    RT_MC(mc_compute_logreg_cost(labels.data(), probs.data(), _ownOutputs.data(), _correctProbs.data(), N, probs.rows(), ST()));
+    double* slot = costSlot();
+    RT_MC(mc_sum_all(_ownOutputs.data(), N, slot, ST()));
+    RT_MC(mc_sum_all(_correctProbs.data(), N, slot + 1, ST()));
+}
+
+void LogregCostLayer::finishCost(double* vals, int numCases) const {
+    vals[0] = -vals[0];                // -sum log p(label)
+    vals[1] = numCases - vals[1];      // number of errors (ties count fractionally)
+}
+
+void LogregCostLayer::bpropActs(DevMat&, int inpIdx, float scaleTargets, PASS_TYPE) {
+    if (inpIdx != 1) throw std::runtime_error("logreg cost: gradient requested for the label input");
+    // a softmax directly below computes the whole gradient itself (layer.cu:1012-1017)
+    const bool doWork = _prev[1]->getNext().size() > 1 || _prev[1]->getType() != "softmax";
+    if (!doWork) return;
+    DevMat& probs = _prev[1]->getActs();
+    RT_MC(mc_compute_logreg_grad(_prev[0]->getActs().data(), probs.data(), _prev[1]->getActsGrad().data(), scaleTargets == 1, _coeff, probs.cols(),
+                                 probs.rows(), ST()));
+}
+
+void SumOfSquaresCostLayer::fpropActs(int, float, PASS_TYPE) {
+    DevMat& x = *_inputs[0];
+    _ownOutputs.resize(x);
+    RT_MC(mc_neuron_activate(MC_N_SQUARE, 0, 0, x.data(), _ownOutputs.data(), x.numel(), ST()));
+    RT_MC(mc_sum_all(_ownOutputs.data(), x.numel(), costSlot(), ST()));
+}
+
+void SumOfSquaresCostLayer::bpropActs(DevMat&, int i, float scaleTargets, PASS_TYPE) {
+    DevMat& tgt = _prev[i]->getActsGrad();
+    if (scaleTargets == 0) RT_MC(mc_scale(tgt.data(), _inputs[0]->data(), -_coeff, tgt.numel(), ST()));
+    else RT_MC(mc_axpby(tgt.data(), _inputs[0]->data(), scaleTargets, -_coeff, tgt.numel(), ST()));
+}
+
+}  // namespace rt

@@ -1,0 +1,429 @@
+// layer.h -- the layer graph of the host runtime.  Semantics follow the reference's
+// Kernel/include/layers/layer.cuh:49-383 + Kernel/src/layers/layer.cu (cited per method);
+// this is also the header a Plugins/*.so author compiles against (Layer, WeightLayer, CostLayer,
+// Neuron are the base classes a plugin subclasses; see csrc/plugins/extralayers.cpp).
+//
+// Differences from the reference that are deliberate:
+//   * activations are DevMat (features, numCases) row-major, no soft transposes;
+//   * every weight tensor keeps an explicit gradient buffer (the reference's useGrad=true
+//     formulation, weights.cuh:150-164, used for ALL layer types) because data parallelism
+//     all-reduces raw gradients; FC / local / cccp in the reference fold the momentum into the
+//     GEMM's beta instead (layer.cu:402-406), which is the same arithmetic on one GPU;
+//   * weights, increments and gradients of the whole net live in three contiguous arenas
+//     (ConvNet::copyToGPU) so gradient all-reduce buckets are address ranges;
+//   * cost values stay on the device until the end of the batch (no per-minibatch sync).
+#pragma once
+#include <Python.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "devmat.h"
+#include "pyutil.h"
+
+namespace rt {
+
+class ConvNet;
+class Layer;
+
+enum PASS_TYPE { PASS_TRAIN, PASS_TEST, PASS_GC };
+
+// ------------------------------------------------------------------------------------------
+// Neuron (Kernel/include/layers/neuron.cuh:65-462): activation functor pair applied by
+// NeuronLayer.  `inputs` and `outputs` may be the same matrix.
+// ------------------------------------------------------------------------------------------
+class Neuron {
+public:
+    virtual ~Neuron() {}
+    virtual void activate(DevMat& inputs, DevMat& outputs, PASS_TYPE passType);
+    // target = (add ? target : 0) + f'(.) * actsGrad ; target may alias actsGrad
+    virtual void computeInputGrad(DevMat& actsGrad, DevMat& target, bool add, PASS_TYPE passType);
+    // The plain relu can be folded into the producing contraction's epilogue.
+    virtual bool isRelu() const { return false; }
+    static Neuron& makeNeuron(PyObject* neuronDict);
+
+protected:
+    DevMat *_inputs = nullptr, *_outputs = nullptr;
+    bool _activated = false;
+    // built-in element-wise neurons are one (type, a, b) triple for the kernel library
+    int _mcType = 0;  // MC_N_IDENT
+    float _a = 0, _b = 0;
+    bool _usesInputs = false;  // gradient needs the neuron's input rather than its output
+    friend class BuiltinNeuron;
+};
+
+// ------------------------------------------------------------------------------------------
+// Weights (Kernel/include/layers/weights.cuh:41-219)
+// ------------------------------------------------------------------------------------------
+class Weights {
+public:
+    // `deviceFortran`: the device copy holds the matrix column-major, i.e. as a row-major
+    // (cols, rows) matrix -- what FC / cccp want, and what their NumPy arrays already are.
+    Weights(HostMat& hW, HostMat& hInc, float eps, float wc, float mom, bool deviceFortran);
+    Weights(Weights& src, float eps);  // shared with another layer's matrix
+    ~Weights();
+
+    float* getW() const { return owner()._w; }
+    float* getInc() const { return owner()._inc; }
+    float* getGrad() const { return owner()._grad; }
+    int getNumRows() const { return _hW->rows(); }   // logical (Python-visible) shape
+    int getNumCols() const { return _hW->cols(); }
+    size_t numel() const { return _hW->numel(); }
+    bool deviceFortran() const { return owner()._devFortran; }
+    bool isOwner() const { return _src == nullptr; }
+    float getEps() const { return _eps; }
+    float getMom() const { return _mom; }
+    float getWC() const { return _wc; }
+    int getNumUpdates() const { return owner()._numUpdates; }
+    int incNumUpdates() { return const_cast<Weights&>(owner())._numUpdates++; }
+    size_t arenaOffset() const { return owner()._offset; }
+
+    void bind(float* w, float* inc, float* grad, size_t offset);  // arena slices (owner only)
+    void copyToGPU();    // owner only; no-op for shared
+    void copyToCPU();
+    void update();       // weights.cuh:150-164, one fused kernel
+    // grad-check support: element (i, j) of the logical matrix <-> device offset
+    size_t deviceIndex(int i, int j) const { return deviceFortran() ? (size_t)j * getNumRows() + i : (size_t)i * getNumCols() + j; }
+    void releaseHost();  // GIL required
+
+private:
+    const Weights& owner() const { return _src ? _src->owner() : *this; }
+    HostMat *_hW, *_hInc;
+    Weights* _src = nullptr;
+    float *_w = nullptr, *_inc = nullptr, *_grad = nullptr;
+    size_t _offset = 0;
+    float _eps, _wc, _mom;
+    bool _devFortran = false;
+    int _numUpdates = 0;
+};
+
+class WeightList {
+public:
+    Weights& operator[](int i) const { return *_list[i]; }
+    ~WeightList() { for (Weights* w : _list) delete w; }
+    void addWeights(Weights& w) { _list.push_back(&w); }
+    int getSize() const { return (int)_list.size(); }
+    void update() { for (Weights* w : _list) w->update(); }
+    void copyToCPU() { for (Weights* w : _list) w->copyToCPU(); }
+    void copyToGPU() { for (Weights* w : _list) w->copyToGPU(); }
+
+private:
+    std::vector<Weights*> _list;
+};
+
+// ------------------------------------------------------------------------------------------
+// Layer (layer.cuh:49-108, layer.cu:45-244)
+// ------------------------------------------------------------------------------------------
+class Layer {
+public:
+    Layer(ConvNet* convNet, PyObject* paramsDict);
+    virtual ~Layer() {}
+
+    virtual void fprop(PASS_TYPE passType);                 // arrival-counted (layer.cu:76-85)
+    void fprop(DevMat& v, PASS_TYPE passType);
+    virtual void fprop(DevMatV& v, PASS_TYPE passType);     // layer.cu:93-115
+    virtual void bprop(PASS_TYPE passType);                 // layer.cu:117-123
+    void bprop(DevMat& v, PASS_TYPE passType);              // layer.cu:125-167
+    virtual void reset();
+    int getRcvdFInputs() const { return _rcvdFInputs; }
+    int getRcvdBInputs() const { return _rcvdBInputs; }
+    int incRcvdBInputs() { return ++_rcvdBInputs; }
+    const std::string& getName() const { return _name; }
+    const std::string& getType() const { return _type; }
+    void addNext(Layer* l);
+    void addPrev(Layer* l) { _prev.push_back(l); }
+    std::vector<Layer*>& getPrev() { return _prev; }
+    std::vector<Layer*>& getNext() { return _next; }
+    virtual DevMat& getActs();
+    virtual DevMat& getActsGrad();
+    int getNumOutputs() const { return _numOutputs; }
+    virtual void postInit();
+    bool isGradConsumer();
+    virtual bool isGradProducer() { return true; }
+
+    // weight layers override these
+    virtual void updateWeights() {}
+    virtual void checkGradients() {}
+    virtual void copyToCPU() {}
+    virtual void copyToGPU() {}
+    virtual void releaseHost() {}   // drop Python references (GIL held)
+
+protected:
+    virtual void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) = 0;
+    virtual void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) = 0;
+    virtual void bpropCommon(DevMat& v, PASS_TYPE passType) {}
+    virtual void truncBwdActs();
+    void fpropNext(PASS_TYPE passType);
+    int numCases() const { return _numCases; }
+
+    ConvNet* _convNet;
+    std::vector<Layer*> _prev, _next;
+    int _rcvdFInputs = 0, _rcvdBInputs = 0;
+    DevMatV _inputs;
+    DevMat *_outputs, *_actsGrad;
+    DevMat _ownOutputs, _ownActsGrad;
+    bool _gradConsumer, _foundGradConsumers = false, _conserveMem;
+    int _numGradProducersNext = 0;
+    int _actsTarget, _actsGradTarget;
+    int _numOutputs, _numCases = 0;
+    std::string _name, _type;
+};
+
+class NeuronLayer : public Layer {
+public:
+    NeuronLayer(ConvNet* convNet, PyObject* paramsDict);
+    Neuron& getNeuron() { return *_neuron; }
+    // set by the producing layer when it already applied this (in-place relu) neuron in its epilogue
+    void setFusedIntoProducer(bool f) { _fused = f; }
+    bool inPlace() const { return _actsTarget == 0; }
+
+protected:
+    void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    Neuron* _neuron;
+    bool _fused = false;
+};
+
+class WeightLayer : public Layer {
+public:
+    // deviceFortran: see Weights.  (The reference's `trans` / `useGrad` arguments are gone:
+    // layout is explicit and every tensor has a gradient buffer.)
+    WeightLayer(ConvNet* convNet, PyObject* paramsDict, bool deviceFortran);
+    void updateWeights() override;
+    void copyToCPU() override;
+    void copyToGPU() override;
+    void checkGradients() override;
+    void releaseHost() override;
+    Weights& getWeights(int idx) { return _weights[idx]; }
+    Weights& getBiases() { return *_biases; }
+    int getNumWeights() const { return _weights.getSize(); }
+
+protected:
+    void bpropCommon(DevMat& v, PASS_TYPE passType) override;   // layer.cu:318-334
+    virtual void bpropBiases(DevMat& v, PASS_TYPE passType) = 0;
+    virtual void bpropWeights(DevMat& v, int inpIdx, PASS_TYPE passType) = 0;
+    // If the only consumer is an in-place plain relu, returns it (epilogue fusion candidate).
+    NeuronLayer* fusableRelu();
+    // scratch for split-K / partial sums, shared by all layers of the net
+    float* workspace(size_t bytes);
+
+    WeightList _weights;
+    Weights* _biases;
+    float _wStep = 0.001f, _bStep = 0.002f;
+};
+
+class FCLayer : public WeightLayer {
+public:
+    FCLayer(ConvNet* convNet, PyObject* paramsDict);
+
+protected:
+    void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    void bpropBiases(DevMat& v, PASS_TYPE passType) override;
+    void bpropWeights(DevMat& v, int inpIdx, PASS_TYPE passType) override;
+};
+
+class LocalLayer : public WeightLayer {
+public:
+    LocalLayer(ConvNet* convNet, PyObject* paramsDict);
+    ~LocalLayer();
+
+protected:
+    intv *_padding, *_stride, *_filterSize, *_channels, *_imgSize, *_groups;
+    intv *_imgPixels, *_filterPixels, *_filterChannels, *_overSample, *_randSparse;
+    int _modulesX, _modules, _numFilters;
+};
+
+class ConvLayer : public LocalLayer {
+public:
+    ConvLayer(ConvNet* convNet, PyObject* paramsDict);
+
+protected:
+    void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    void bpropBiases(DevMat& v, PASS_TYPE passType) override;
+    void bpropWeights(DevMat& v, int inpIdx, PASS_TYPE passType) override;
+    int _partialSum;
+    bool _sharedBiases;
+};
+
+class LocalUnsharedLayer : public LocalLayer {
+public:
+    LocalUnsharedLayer(ConvNet* convNet, PyObject* paramsDict);
+
+protected:
+    void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    void bpropBiases(DevMat& v, PASS_TYPE passType) override;
+    void bpropWeights(DevMat& v, int inpIdx, PASS_TYPE passType) override;
+};
+
+class SoftmaxLayer : public Layer {
+public:
+    SoftmaxLayer(ConvNet* convNet, PyObject* paramsDict) : Layer(convNet, paramsDict) {}
+
+protected:
+    void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+};
+
+class EltwiseSumLayer : public Layer {
+public:
+    EltwiseSumLayer(ConvNet* convNet, PyObject* paramsDict);
+    ~EltwiseSumLayer() { delete _coeffs; }
+
+protected:
+    void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    floatv* _coeffs;
+};
+
+class DataLayer : public Layer {
+public:
+    DataLayer(ConvNet* convNet, PyObject* paramsDict);
+    void fprop(PASS_TYPE passType) override;
+    void fprop(DevMatV& data, PASS_TYPE passType) override;
+    bool isGradProducer() override { return false; }
+
+protected:
+    void fpropActs(int, float, PASS_TYPE) override {}
+    void bpropActs(DevMat&, int, float, PASS_TYPE) override {}
+    int _dataIdx;
+};
+
+class PoolLayer : public Layer {
+public:
+    PoolLayer(ConvNet* convNet, PyObject* paramsDict);
+    static PoolLayer& makePoolLayer(ConvNet* convNet, PyObject* paramsDict);
+
+protected:
+    int _channels, _sizeX, _start, _stride, _outputsX, _imgSize;
+    std::string _pool;
+};
+
+class AvgPoolLayer : public PoolLayer {
+public:
+    AvgPoolLayer(ConvNet* convNet, PyObject* paramsDict) : PoolLayer(convNet, paramsDict) {}
+
+protected:
+    void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+};
+
+class MaxPoolLayer : public PoolLayer {
+public:
+    MaxPoolLayer(ConvNet* convNet, PyObject* paramsDict) : PoolLayer(convNet, paramsDict) {}
+
+protected:
+    void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+};
+
+class ResponseNormLayer : public Layer {
+public:
+    ResponseNormLayer(ConvNet* convNet, PyObject* paramsDict);
+
+protected:
+    void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    void truncBwdActs() override;
+    int _channels, _size, _imgSize;
+    float _scale, _pow;
+    DevMat _denoms;
+};
+
+class CrossMapResponseNormLayer : public ResponseNormLayer {
+public:
+    CrossMapResponseNormLayer(ConvNet* convNet, PyObject* paramsDict);
+
+protected:
+    void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    bool _blocked;
+    float _k;
+};
+
+class ContrastNormLayer : public ResponseNormLayer {
+public:
+    ContrastNormLayer(ConvNet* convNet, PyObject* paramsDict) : ResponseNormLayer(convNet, paramsDict) {}
+
+protected:
+    void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    void truncBwdActs() override;
+    DevMat _meanDiffs;
+};
+
+// ------------------------------------------------------------------------------------------
+// Cost layers (layer.cuh:330-383, layer.cu:948-1036).  A cost layer writes its values for
+// minibatch m into device slot m; ConvNet reads all slots once per batch.
+// ------------------------------------------------------------------------------------------
+class CostLayer : public Layer {
+public:
+    CostLayer(ConvNet* convNet, PyObject* paramsDict);
+    ~CostLayer();
+    void bprop(PASS_TYPE passType) override;
+    bool isGradProducer() override { return _coeff != 0; }
+    float getCoeff() const { return _coeff; }
+    virtual int numCostValues() const = 0;
+    // Host-side fix-up of the raw device sums of one minibatch (e.g. negate, numCases - x).
+    virtual void finishCost(double* vals, int numCases) const {}
+    double* costSlot();          // device address of this minibatch's values
+    static CostLayer& makeCostLayer(ConvNet* convNet, const std::string& type, PyObject* paramsDict);
+    static const int MAX_SLOTS = 4096;
+    double* deviceSlots() const { return _slots; }
+
+protected:
+    float _coeff;
+    double* _slots = nullptr;    // MAX_SLOTS * numCostValues() doubles on the device
+};
+
+class LogregCostLayer : public CostLayer {
+public:
+    LogregCostLayer(ConvNet* convNet, PyObject* paramsDict) : CostLayer(convNet, paramsDict) {}
+    int numCostValues() const override { return 2; }
+    void finishCost(double* vals, int numCases) const override;
+
+protected:
+    void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    DevMat _correctProbs;
+};
+
+class SumOfSquaresCostLayer : public CostLayer {
+public:
+    SumOfSquaresCostLayer(ConvNet* convNet, PyObject* paramsDict) : CostLayer(convNet, paramsDict) {}
+    int numCostValues() const override { return 1; }
+    void finishCost(double* vals, int numCases) const override { vals[0] *= 0.5; }
+
+protected:
+    void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+};
+
+// ------------------------------------------------------------------------------------------
+// Uniform [0,1) numbers for stochastic neurons (the reference's NVMatrix::randomizeUniform,
+// nvmatrix.cu:271-300: XORWOW states seeded from the wall clock).  Here: a counter-based Philox
+// stream (seed, running offset), so a run is reproducible from its seed; tests may queue
+// explicit masks, which are consumed first, in fprop order.
+// ------------------------------------------------------------------------------------------
+void fillUniform(DevMat& m);
+void injectUniform(const float* host, size_t n);
+void setRandSeed(unsigned long long seed);
+
+// ------------------------------------------------------------------------------------------
+// Plugin ABI (Kernel/include/convnet/plugin.cuh:33-41): a Plugins/*.so exports
+//   extern "C" std::map<std::string, layerConFunc>  layerConstructor();
+//   extern "C" std::map<std::string, neuronConFunc> neuronConstructor();
+// keyed by the `type` strings of the layer-def file.
+// ------------------------------------------------------------------------------------------
+typedef Layer* (*layerConFunc)(ConvNet*, PyObject*);
+typedef Neuron* (*neuronConFunc)(PyObject*);
+std::map<std::string, layerConFunc>& pluginLayers();
+std::map<std::string, neuronConFunc>& pluginNeurons();
+// Scans `dir` (default "Plugins" next to the module, then ./Plugins as the reference does,
+// plugin.cu:40-70) and merges every plugin's constructors.  Returns the number of files loaded.
+int loadPlugins(const char* moduleDir);
+
+}  // namespace rt
