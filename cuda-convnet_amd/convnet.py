@@ -25,25 +25,18 @@ from options import BooleanOptionParser, IntegerOptionParser, ListOptionParser, 
 from util import is_windows_machine
 
 
+import dp
+
+
 def dp_env():
-    """(rank, world_size, local_rank) of a torch.distributed.run launch; (0, 1, 0) otherwise."""
-    return (int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0)))
+    return dp.env()
 
 
 def shard_batch(mats, minibatch, rank, world):
-    """Rank `rank`'s cases of a (dims, cases) batch list: global minibatch i = cases
-    [i*minibatch*world, (i+1)*minibatch*world); this rank takes the `rank`-th of `world` equal
-    slices of it (a trailing partial minibatch is split the same way; cases that do not divide
-    evenly are dropped)."""
+    """Rank `rank`'s cases of a (dims, cases) batch list (see dp.shard_columns)."""
     if world == 1:
         return mats
-    cases = mats[0].shape[1]
-    gmb = minibatch * world
-    cols = []
-    for s in range(0, cases, gmb):
-        per = (min(cases, s + gmb) - s) // world
-        cols.append(n.arange(s + rank * per, s + (rank + 1) * per))
-    cols = n.concatenate(cols)
+    cols = dp.shard_columns(mats[0].shape[1], minibatch, rank, world)
     return [n.require(x[:, cols], dtype=n.single, requirements="C") for x in mats]
 
 
@@ -53,6 +46,8 @@ class ConvNet(IGPUModel):
         dp_params["multiview_test"] = op.get_value("multiview_test")
         dp_params["crop_border"] = op.get_value("crop_border")
         self.rank, self.world, self.local_rank = dp_env()
+        if self.world > 1:
+            import torch  # noqa: F401  (before libkernel: both must share one HIP runtime, torch's)
         IGPUModel.__init__(self, "ConvNet", op, load_dic, [], dp_params=dp_params)
 
     def import_model(self):
@@ -64,7 +59,6 @@ class ConvNet(IGPUModel):
     def init_model_lib(self):
         dev = self.device_ids[0]
         if self.world > 1:
-            import dp
             dev = self.local_rank if dev < 0 else dev
             self.libmodel.initModel(self.layers, self.minibatch_size, dev)
             dp.connect(self.libmodel, self.rank, self.world)

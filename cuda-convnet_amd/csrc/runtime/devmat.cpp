@@ -2,6 +2,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 namespace rt {
 
@@ -17,6 +18,57 @@ std::string fmt(const char* f, ...) {
 static thread_local hipStream_t t_stream = nullptr;
 hipStream_t computeStream() { return t_stream; }
 void setComputeStream(hipStream_t s) { t_stream = s; }
+
+// ---- per-launch timing ---------------------------------------------------------------------
+namespace {
+struct ProfRec { std::string key; hipEvent_t a, b; };
+std::vector<ProfRec> g_prof;
+std::string g_profFilter, g_profLayer;
+bool g_profOn = false;
+}  // namespace
+
+void profileSetFilter(const char* filter) {
+    g_profFilter = filter ? filter : "";
+    g_profOn = !g_profFilter.empty();
+}
+
+void profileSetLayer(const char* layerName) {
+    if (g_profOn) g_profLayer = layerName ? layerName : "";
+}
+
+ProfScope::ProfScope(const char* callText) {
+    if (!g_profOn) return;
+    const char* paren = strchr(callText, '(');
+    std::string key = g_profLayer + ":" + std::string(callText, paren ? (size_t)(paren - callText) : strlen(callText));
+    if (g_profFilter != "*" && key.find(g_profFilter) == std::string::npos) return;
+    ProfRec r;
+    r.key = key;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, computeStream());
+    g_prof.push_back(r);
+    _slot = (int)g_prof.size() - 1;
+}
+
+ProfScope::~ProfScope() {
+    if (_slot >= 0) (void)hipEventRecord(g_prof[_slot].b, computeStream());
+}
+
+void profileReport(std::map<std::string, std::pair<long, double>>& out, bool reset) {
+    (void)hipStreamSynchronize(computeStream());
+    for (ProfRec& r : g_prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            auto& e = out[r.key];
+            e.first += 1;
+            e.second += ms;
+        }
+        if (reset) {
+            (void)hipEventDestroy(r.a);
+            (void)hipEventDestroy(r.b);
+        }
+    }
+    if (reset) g_prof.clear();
+}
 
 DeviceAllocator& DeviceAllocator::get() {
     static DeviceAllocator a;

@@ -29,10 +29,25 @@ std::string fmt(const char* f, ...);
             throw std::runtime_error(::rt::fmt("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__)); \
     } while (0)
 
+// Optional per-launch timing (bench.py's roofline leg): when a filter is set, every RT_MC call
+// whose "<layer>:<function>" key contains the filter is bracketed by two HIP events on the
+// compute stream; profileReport() turns them into (launches, total ms) per key.
+class ProfScope {
+public:
+    explicit ProfScope(const char* callText);
+    ~ProfScope();
+private:
+    int _slot = -1;
+};
+void profileSetFilter(const char* filter);            // NULL / "" switches profiling off
+void profileSetLayer(const char* layerName);
+void profileReport(std::map<std::string, std::pair<long, double>>& out, bool reset);
+
 // Every kernel call of the runtime goes through this: a rejected call is a bug in the caller's
 // shapes, reported with the library's own message.
 #define RT_MC(call)                                                                                \
     do {                                                                                           \
+        ::rt::ProfScope prof__(#call);                                                             \
         int rc__ = (call);                                                                         \
         if (rc__ != MC_OK)                                                                         \
             throw std::runtime_error(::rt::fmt("%s -> %d: %s (%s:%d)", #call, rc__, mc_last_error(), __FILE__, __LINE__)); \

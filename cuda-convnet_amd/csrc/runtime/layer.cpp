@@ -60,6 +60,7 @@ void Layer::fprop(DevMatV& v, PASS_TYPE passType) {
                                          _prev[i]->getNumOutputs(), _numCases));
     if (_actsTarget < 0 && _numOutputs > 0) _ownOutputs.resize(_numOutputs, _numCases);
 
+    profileSetLayer(_name.c_str());
     // the input whose matrix this layer writes into goes first, the others accumulate
     if (_actsTarget >= 0) fpropActs(_actsTarget, 0, passType);
     for (int i = 0; i < (int)_prev.size(); i++)
@@ -75,6 +76,7 @@ void Layer::bprop(PASS_TYPE passType) {
 }
 
 void Layer::bprop(DevMat& v, PASS_TYPE passType) {
+    profileSetLayer(_name.c_str());
     bpropCommon(v, passType);
     if (isGradProducer()) {
         auto send = [&](int i) {
@@ -365,6 +367,7 @@ void WeightLayer::bpropCommon(DevMat& v, PASS_TYPE passType) {
 }
 
 void WeightLayer::updateWeights() {
+    profileSetLayer(_name.c_str());
     _weights.update();
     _biases->update();
 }

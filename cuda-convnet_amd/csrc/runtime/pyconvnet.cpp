@@ -303,6 +303,32 @@ static PyObject* getActs(PyObject*, PyObject* args) {
     return copy;
 }
 
+// setProfile(filter): time every kernel launch whose "<layer>:<mc_function>" key contains `filter`
+// ("*" = all, "" = off) with HIP events on the compute stream
+static PyObject* setProfile(PyObject*, PyObject* args) {
+    REQUIRE_MODEL();
+    const char* filter;
+    if (!PyArg_ParseTuple(args, "s", &filter)) return nullptr;
+    const std::string f(filter);
+    return run_on_device([=] { profileSetFilter(f.c_str()); });
+}
+
+// getProfile() -> {key: (launches, total_ms)}; clears the records
+static PyObject* getProfile(PyObject*, PyObject*) {
+    REQUIRE_MODEL();
+    std::map<std::string, std::pair<long, double>> rep;
+    PyObject* ok = run_on_device([&] { profileReport(rep, true); });
+    if (!ok) return nullptr;
+    Py_DECREF(ok);
+    PyObject* dict = PyDict_New();
+    for (auto& kv : rep) {
+        PyObject* v = Py_BuildValue("(ld)", kv.second.first, kv.second.second);
+        PyDict_SetItemString(dict, kv.first.c_str(), v);
+        Py_DECREF(v);
+    }
+    return dict;
+}
+
 static PyMethodDef methods[] = {{"initModel", initModel, METH_VARARGS, nullptr},
                                 {"startBatch", startBatch, METH_VARARGS, nullptr},
                                 {"finishBatch", finishBatch, METH_VARARGS, nullptr},
@@ -316,6 +342,8 @@ static PyMethodDef methods[] = {{"initModel", initModel, METH_VARARGS, nullptr},
                                 {"setDropoutMasks", setDropoutMasks, METH_VARARGS, nullptr},
                                 {"setSeed", setSeed, METH_VARARGS, nullptr},
                                 {"getActs", getActs, METH_VARARGS, nullptr},
+                                {"setProfile", setProfile, METH_VARARGS, nullptr},
+                                {"getProfile", getProfile, METH_NOARGS, nullptr},
                                 {nullptr, nullptr, 0, nullptr}};
 
 static struct PyModuleDef moduledef = {PyModuleDef_HEAD_INIT, "libkernel", "MI355X conv-net training runtime (cuda-convnet extension API)", -1, methods};
