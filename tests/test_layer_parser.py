@@ -1,0 +1,107 @@
+"""Config front end: layer-def / layer-params files -> layer dicts (Python/layer.py of the reference).
+The shipped reference files are parsed unchanged when the reference tree is present and must give
+the same model as this repo's own copies of the BASELINE networks."""
+import os
+
+import numpy as np
+import pytest
+
+import modelutil
+
+REF = "/root/reference"
+
+
+def test_nin_shapes():
+    layers, dims, classes = modelutil.load_net("nin")
+    by = dict((l["name"], l) for l in layers)
+    assert [l["name"] for l in layers][:6] == ["data", "labels", "conv1", "conv1_neuron", "cccp1", "cccp1_neuron"]
+    assert by["conv1"]["outputs"] == 192 * 32 * 32 and by["conv1"]["modulesX"] == 32 and by["conv1"]["padding"] == [-2]
+    assert by["conv1"]["weights"][0].shape == (75, 192) and by["conv1"]["weights"][0].flags["C_CONTIGUOUS"]
+    assert by["cccp1"]["weights"][0].shape == (192, 160) and by["cccp1"]["weights"][0].flags["F_CONTIGUOUS"]
+    assert by["cccp1"]["biases"].shape == (1, 160)
+    assert by["pool1"]["outputsX"] == 16 and by["pool2"]["outputsX"] == 8 and by["poolg"]["outputsX"] == 1
+    assert by["dropout1"]["neuron"] == {"type": "dropout", "params": {"prob": 0.5}, "usesActs": False, "usesInputs": False}
+    # in-place relu after every weight layer; dropout shares only the gradient (pool "uses" its acts)
+    assert by["conv1_neuron"]["actsTarget"] == 0 and by["conv1_neuron"]["actsGradTarget"] == 0
+    assert by["dropout1"]["actsTarget"] == -1 and by["dropout1"]["actsGradTarget"] == 0
+    assert by["logprob"]["inputs"] == [1, 25] and by["logprob"]["coeff"] == 0.1
+    n = sum(w.size for l in layers if "weights" in l for w in l["weights"] + [l["biases"]])
+    assert n == 966986
+    assert by["cccp6"]["epsW"] == [0.1] and by["conv1"]["wc"] == [0.00001]
+
+
+@pytest.mark.parametrize("name,params", [("80sec", 145578), ("conv-local", 1901386), ("imagenet", 50351076), ("18pct", 89578)])
+def test_parameter_counts(name, params):
+    layers, _, _ = modelutil.load_net(name)
+    assert sum(w.size for l in layers if "weights" in l for w in l["weights"] + [l["biases"]]) == params
+
+
+def test_norm_scale_and_default_k():
+    layers, _, _ = modelutil.load_net("imagenet")
+    r = [l for l in layers if l["name"] == "rnorm1"][0]
+    assert r["type"] == "cmrnorm" and abs(r["scale"] - 0.0001 / 5) < 1e-12 and r["k"] == 1.0 and r["pow"] == 0.75
+    layers, _, _ = modelutil.load_net("18pct")
+    r = [l for l in layers if l["name"] == "rnorm1"][0]
+    assert abs(r["scale"] - 0.00005 / 9) < 1e-15
+
+
+def test_neuron_strings():
+    import layer
+    def parse(s):
+        for p in layer.neuron_parsers:
+            r = p.parse(s)
+            if r:
+                return r
+    assert parse("tanh[1.79,-0.66]")["params"] == {"a": 1.79, "b": -0.66}
+    assert parse("relu")["type"] == "relu" and parse("brelu[6]")["params"] == {"a": 6.0}
+    assert parse("dropout[0.5]")["type"] == "dropout"
+    assert parse("nosuch") is None and parse("tanh[1]") is None
+
+
+def test_parse_errors_exit(tmp_path, capsys):
+    import layer
+    d = tmp_path / "bad.def"
+    d.write_text("[data]\ntype=data\ndataIdx=0\n[c]\ntype=conv\ninputs=nothere\n")
+    p = tmp_path / "bad.params"
+    p.write_text("")
+    m = modelutil._Model()
+    m.train_data_provider = modelutil.ShapeProvider(3072, 10)
+    with pytest.raises(SystemExit):
+        layer.LayerParser.parse_layers(str(d), str(p), m)
+    assert "input layer 'nothere' not defined" in capsys.readouterr().out
+
+
+REF_PAIRS = [("nin", "NIN/cifar-10_def", "NIN/cifar-10_params"), ("80sec", "example-layers/layers-80sec.cfg", "example-layers/layer-params-80sec.cfg"),
+             ("conv-local", "example-layers/layers-conv-local-13pct.cfg", "example-layers/layer-params-conv-local-13pct.cfg"),
+             ("imagenet", "example-layers/imagenet", "example-layers/imagenet_params"),
+             ("18pct", "example-layers/layers-18pct.cfg", "example-layers/layer-params-18pct.cfg")]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
+@pytest.mark.parametrize("name,rdef,rparams", REF_PAIRS)
+def test_reference_config_files_parse_unchanged(name, rdef, rparams):
+    mine, dims, classes = modelutil.load_net(name, seed=3)
+    theirs = modelutil.parse_net(os.path.join(REF, rdef), os.path.join(REF, rparams), dims, classes, seed=3)
+    assert [l["name"] for l in mine] == [l["name"] for l in theirs]
+    for a, b in zip(mine, theirs):
+        assert sorted(a.keys()) == sorted(b.keys()), a["name"]
+        for k in a:
+            if k in ("inputLayers",):
+                continue
+            if isinstance(a[k], np.ndarray):
+                np.testing.assert_array_equal(a[k], b[k])
+            elif k in ("weights", "weightsInc"):
+                for x, y in zip(a[k], b[k]):
+                    np.testing.assert_array_equal(x, y)
+            elif k == "partialSum":
+                continue      # a tuning knob of the reference's kernels; this runtime picks its own split
+            else:
+                assert a[k] == b[k], (a["name"], k, a[k], b[k])
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
+def test_reference_gc_config_parses():
+    layers = modelutil.parse_net(os.path.join(REF, "example-layers/layers.gc.cfg"), os.path.join(REF, "example-layers/layer-params.gc.cfg"), 3072, 10)
+    by = dict((l["name"], l) for l in layers)
+    assert by["local32"]["randSparse"] == [True] and len(by["local32"]["filterConns"][0]) == by["local32"]["groups"][0] * by["local32"]["filterChannels"][0]
+    assert by["avgpool"]["start"] == -2 and by["fc10"]["inputs"] == [6, 3] or by["fc10"]["numInputs"] == [by["local32"]["outputs"], by["conv32"]["outputs"]]
