@@ -67,8 +67,8 @@ class ConvNet(IGPUModel):
 
     def init_model_state(self):
         ms = self.model_state
-        if self.world > 1 and not self.load_file:
-            nr.seed(int(os.environ.get("CONVNET_SEED", 1)))      # identical initial weights on every rank
+        if not self.load_file and (self.world > 1 or "CONVNET_SEED" in os.environ):
+            nr.seed(int(os.environ.get("CONVNET_SEED", 1)))      # identical initial weights on every rank / reproducible runs
         if self.load_file:
             ms["layers"] = lay.LayerParser.parse_layers(self.layer_def, self.layer_params, self, ms["layers"])
         else:
@@ -120,7 +120,9 @@ class ConvNet(IGPUModel):
         data = shard_batch(batch_data[2], self.minibatch_size, self.rank, self.world)
         self._held_batch = data          # the native module keeps views of these arrays until finishBatch
         if self.check_grads:
-            self.libmodel.checkGradients(data)
+            self.libmodel.checkGradients(data)    # prints the report; the reference's worker exits the process here
+            sys.stdout.flush()
+            sys.exit(0)
         elif not train and self.multiview_test:
             self.libmodel.startMultiviewTest(data, self.train_data_provider.num_views, self.logreg_idx)
         else:

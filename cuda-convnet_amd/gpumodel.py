@@ -42,7 +42,7 @@ class IGPUModel(object):
             self.model_state = {}
             if filename_options is not None:
                 tags = ["%s_%s" % (char, self.options[opt].get_str_value()) for opt, char in filename_options]
-                self.save_file = "_".join([model_name] + tags + [strftime("%Y-%m-%d_%H.%M.%S")])
+                self.save_file = model_name + "_" + "_".join(tags) + "_" + strftime("%Y-%m-%d_%H.%M.%S")
             self.model_state["train_outputs"] = []
             self.model_state["test_outputs"] = []
             self.model_state["epoch"] = 1
