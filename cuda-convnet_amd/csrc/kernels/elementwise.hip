@@ -257,6 +257,31 @@ __global__ void __launch_bounds__(RED_T) k_sum_all(const float* __restrict__ v, 
 // ---------------------------------------------------------------- axpby / update
 struct FAxpby { float sy, sx; __device__ float operator()(float x, float y) const { return sy * y + sx * x; } };
 
+// One launch for every tensor of the net: workgroup b updates span b of the arenas.  Spans never
+// straddle tensors, start 16-byte aligned, and carry their tensor's hyper-parameters.
+__global__ void k_weights_update_spans(float* w, float* inc, const float* __restrict__ grad, const mcUpdateSpan* __restrict__ spans) {
+    const mcUpdateSpan sp = spans[blockIdx.x];
+    float* W = w + sp.start;
+    float* I = inc + sp.start;
+    const float* G = grad + sp.start;
+    const unsigned n4 = sp.count / 4;
+    for (unsigned v = threadIdx.x; v < n4; v += blockDim.x) {
+        float4 ww = reinterpret_cast<float4*>(W)[v], ii = reinterpret_cast<float4*>(I)[v];
+        const float4 gg = reinterpret_cast<const float4*>(G)[v];
+        ii.x = sp.mom * ii.x + gg.x; ii.y = sp.mom * ii.y + gg.y; ii.z = sp.mom * ii.z + gg.z; ii.w = sp.mom * ii.w + gg.w;
+        if (sp.wceps != 0.f) { ii.x += sp.wceps * ww.x; ii.y += sp.wceps * ww.y; ii.z += sp.wceps * ww.z; ii.w += sp.wceps * ww.w; }
+        ww.x += ii.x; ww.y += ii.y; ww.z += ii.z; ww.w += ii.w;
+        reinterpret_cast<float4*>(I)[v] = ii;
+        reinterpret_cast<float4*>(W)[v] = ww;
+    }
+    for (unsigned v = n4 * 4 + threadIdx.x; v < sp.count; v += blockDim.x) {
+        float ii = sp.mom * I[v] + G[v];
+        if (sp.wceps != 0.f) ii += sp.wceps * W[v];
+        I[v] = ii;
+        W[v] += ii;
+    }
+}
+
 __global__ void k_weights_update(float* w, float* inc, const float* __restrict__ grad, size_t n, float mom, float wceps, bool vec4) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -440,9 +465,45 @@ int mc_sum_rows(const float* v, float* out, int rows, int cols, float sT, float 
     return launch_status("mc_sum_rows");
 }
 
+// rows >> 1: workgroup = 16 float4 columns x 16 row groups; each thread adds rows rg, rg+16, ...
+// in order, then the 16 partials of a column are added in a fixed tree -> run-to-run deterministic.
+__global__ void __launch_bounds__(256) k_sum_cols4_tall(const float4* __restrict__ v, float4* out, int rows, int cols4, float sT, float sO) {
+    __shared__ float4 sh[16][17];
+    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cg;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < cols4)
+        for (int r = rg; r < rows; r += 16) {
+            const float4 x = v[(size_t)r * cols4 + c];
+            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        }
+    sh[rg][cg] = acc;
+    __syncthreads();
+    for (int half = 8; half > 0; half >>= 1) {
+        if (rg < half) {
+            const float4 a = sh[rg][cg], b = sh[rg + half][cg];
+            sh[rg][cg] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        }
+        __syncthreads();
+    }
+    if (rg == 0 && c < cols4) {
+        const float4 t = sh[0][cg];
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sT != 0.f) {
+            o = out[c];
+            o.x *= sT; o.y *= sT; o.z *= sT; o.w *= sT;
+        }
+        o.x += sO * t.x; o.y += sO * t.y; o.z += sO * t.z; o.w += sO * t.w;
+        out[c] = o;
+    }
+}
+
 int mc_sum_cols(const float* v, float* out, int rows, int cols, float sT, float sO, mcStream_t s) {
     MC_REQUIRE(v && out && rows > 0 && cols > 0, "mc_sum_cols: bad arguments");
-    if (cols % 4 == 0 && aligned16(v) && aligned16(out))
+    if (cols % 4 == 0 && aligned16(v) && aligned16(out) && rows >= 32)
+        hipLaunchKernelGGL(k_sum_cols4_tall, dim3(ceil_div(cols / 4, 16)), dim3(256), 0, S(s), reinterpret_cast<const float4*>(v),
+                           reinterpret_cast<float4*>(out), rows, cols / 4, sT, sO);
+    else if (cols % 4 == 0 && aligned16(v) && aligned16(out))
         hipLaunchKernelGGL(k_sum_cols4, dim3(grid_for(cols / 4)), dim3(TPB), 0, S(s), reinterpret_cast<const float4*>(v),
                            reinterpret_cast<float4*>(out), rows, cols / 4, sT, sO);
     else
@@ -474,6 +535,14 @@ int mc_weights_update(float* w, float* inc, const float* grad, size_t n, float m
     hipLaunchKernelGGL(k_weights_update, dim3(grid_for(v4 ? (n + 3) / 4 : n)), dim3(TPB), 0, S(s), w, inc, grad, n, mom,
                        wceps, v4);
     return launch_status("mc_weights_update");
+}
+
+int mc_weights_update_spans(float* weights, float* inc, const float* grad, const mcUpdateSpan* spansDevice, int numSpans, mcStream_t s) {
+    MC_REQUIRE(weights && inc && grad && spansDevice, "mc_weights_update_spans: null pointer");
+    MC_REQUIRE(aligned16(weights) && aligned16(inc) && aligned16(grad), "mc_weights_update_spans: arenas must be 16-byte aligned");
+    if (numSpans <= 0) return MC_OK;
+    hipLaunchKernelGGL(k_weights_update_spans, dim3(numSpans), dim3(TPB), 0, S(s), weights, inc, grad, spansDevice);
+    return launch_status("mc_weights_update_spans");
 }
 
 int mc_softmax(const float* input, float* target, int numCases, int numOut, mcStream_t s) {

@@ -23,6 +23,7 @@
 //   * blockIdx.z = (k-chunk q, group g): k-chunks give deterministic split-K (each chunk writes
 //     its own slab; the reference's partialSum layout is exactly that), groups are independent
 //     GEMMs on disjoint channel/filter ranges.
+#include <stdlib.h>
 #include "mc_common.h"
 
 namespace mc {
@@ -31,6 +32,9 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int THREADS = 256;
+#ifndef MC_BK
+#define MC_BK 16   // k extent of one LDS tile for the contractions whose operands are not both k-contiguous
+#endif
 
 struct ConvG {
     int N, H, W;      // numImages, imgSizeY, imgSizeX
@@ -204,33 +208,45 @@ struct Loader {
         }
     }
 
-    __device__ __forceinline__ void fetch(const P& p, const ConvG& cg, int g, int k0, int kend, int x0, int tid) {
+    // one chunk ("piece" `it`) of the tile: address arithmetic + predicated global load
+    __device__ __forceinline__ void fetch_one(int it, const P& p, const ConvG& cg, int g, int k0, int kend, int x0, int tid) {
         const float* base = ADDR::base(p);
+        const int c = tid + it * THREADS;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (CHUNKS % THREADS == 0 || c < CHUNKS) {
+            int dk, dx;
+            chunk_pos(c, dk, dx);
+            const int k = k0 + dk, x = x0 + dx;
+            if (VEC == 4) {
+                int off;
+                const bool ok = ADDR::addr(p, cg, g, k, x, off) & (k < kend);
+                if (ok) v = *reinterpret_cast<const float4*>(base + off);
+            } else {
+                float e[4];
 #pragma unroll
-        for (int it = 0; it < NCH; ++it) {
-            const int c = tid + it * THREADS;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (CHUNKS % THREADS == 0 || c < CHUNKS) {
-                int dk, dx;
-                chunk_pos(c, dk, dx);
-                const int k = k0 + dk, x = x0 + dx;
-                if (VEC == 4) {
+                for (int u = 0; u < 4; ++u) {
+                    const int ku = KC ? k + u : k, xu = KC ? x : x + u;
                     int off;
-                    const bool ok = ADDR::addr(p, cg, g, k, x, off) & (k < kend);
-                    if (ok) v = *reinterpret_cast<const float4*>(base + off);
-                } else {
-                    float e[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int ku = KC ? k + u : k, xu = KC ? x : x + u;
-                        int off;
-                        const bool ok = ADDR::addr(p, cg, g, ku, xu, off) & (ku < kend);
-                        e[u] = ok ? base[off] : 0.f;
-                    }
-                    v = make_float4(e[0], e[1], e[2], e[3]);
+                    const bool ok = ADDR::addr(p, cg, g, ku, xu, off) & (ku < kend);
+                    e[u] = ok ? base[off] : 0.f;
                 }
+                v = make_float4(e[0], e[1], e[2], e[3]);
             }
-            r[it] = v;
+        }
+        r[it] = v;
+    }
+
+    __device__ __forceinline__ void fetch(const P& p, const ConvG& cg, int g, int k0, int kend, int x0, int tid) {
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) fetch_one(it, p, cg, g, k0, kend, x0, tid);
+    }
+
+    __device__ __forceinline__ void commit_one(int it, float* lds, int tid) const {
+        float4* l4 = reinterpret_cast<float4*>(lds);
+        const int c = tid + it * THREADS;
+        if (CHUNKS % THREADS == 0 || c < CHUNKS) {
+            if (KC) l4[(c % (BK / 4)) * ROWSP + c / (BK / 4)] = r[it];
+            else l4[c] = r[it];
         }
     }
 
@@ -296,46 +312,67 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         const float* cA = (t & 1) ? sA1 : sA0;
         const float* cB = (t & 1) ? sB1 : sB0;
         const bool more = t + 1 < nk;
-        if (more) {
-            la.fetch(pa, cg, g, kbeg + (t + 1) * BK, kend, i0, tid);
-            lb.fetch(pb, cg, g, kbeg + (t + 1) * BK, kend, j0, tid);
-        }
-#pragma unroll
-        for (int k8 = 0; k8 < BK / 8; ++k8) {
-            float af[MT][4], bf[NT][4];
+        float* nA = (t & 1) ? sA0 : sA1;
+        float* nB = (t & 1) ? sB0 : sB1;
+        const int knext = kbeg + (t + 1) * BK;
+        // LDS -> register fragments, software-pipelined: "slab" s holds the operands of one MFMA
+        // k-step (2 k values: lane half h supplies k = kof(s) + h-dependent offset).  The reads of
+        // slab s+PF are issued before the MFMAs of slab s, so the ~100-cycle LDS latency hides
+        // behind PF * MT*NT * 64 cycles of matrix work instead of stalling every other MFMA.
+        constexpr int SLABS = BK / 2, PF = 2;
+        float af[SLABS][MT], bf[SLABS][NT];
+        auto load_slab = [&](int s_) {
+            // slab s_ = (k8, e): k = k8*8 + 4*h + e.  NAT operands read one float per slab; KC
+            // operands fetch the four slabs of a k8 group with one ds_read_b128 when e == 0.
+            const int k8 = s_ >> 2, e = s_ & 3;
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
                 const int row = (wm * MT + a) * 32 + l31;
                 if (LA::KC) {
-                    const float4 v = reinterpret_cast<const float4*>(cA)[(k8 * 2 + h) * LA::ROWSP + row];
-                    af[a][0] = v.x; af[a][1] = v.y; af[a][2] = v.z; af[a][3] = v.w;
+                    if (e == 0) {
+                        const float4 v = reinterpret_cast<const float4*>(cA)[(k8 * 2 + h) * LA::ROWSP + row];
+                        af[s_][a] = v.x; af[s_ + 1][a] = v.y; af[s_ + 2][a] = v.z; af[s_ + 3][a] = v.w;
+                    }
                 } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) af[a][e] = cA[(k8 * 8 + 4 * h + e) * BM + row];
+                    af[s_][a] = cA[(k8 * 8 + 4 * h + e) * BM + row];
                 }
             }
 #pragma unroll
             for (int b = 0; b < NT; ++b) {
                 const int col = (wn * NT + b) * 32 + l31;
                 if (LB::KC) {
-                    const float4 v = reinterpret_cast<const float4*>(cB)[(k8 * 2 + h) * LB::ROWSP + col];
-                    bf[b][0] = v.x; bf[b][1] = v.y; bf[b][2] = v.z; bf[b][3] = v.w;
+                    if (e == 0) {
+                        const float4 v = reinterpret_cast<const float4*>(cB)[(k8 * 2 + h) * LB::ROWSP + col];
+                        bf[s_][b] = v.x; bf[s_ + 1][b] = v.y; bf[s_ + 2][b] = v.z; bf[s_ + 3][b] = v.w;
+                    }
                 } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) bf[b][e] = cB[(k8 * 8 + 4 * h + e) * BN + col];
+                    bf[s_][b] = cB[(k8 * 8 + 4 * h + e) * BN + col];
                 }
             }
+        };
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+        for (int s_ = 0; s_ < PF; ++s_) load_slab(s_);
+        // Next tile: all global loads are issued before this tile's MFMAs and stored to the idle LDS
+        // buffer after them.  (Spreading the loads / stores between the slabs was measured: no gain for
+        // the forward kernel, -15 % for the weight-gradient kernel, whose loads then land too late.)
+        if (more) {
+            la.fetch(pa, cg, g, knext, kend, i0, tid);
+            lb.fetch(pb, cg, g, knext, kend, j0, tid);
+        }
 #pragma unroll
-                for (int a = 0; a < MT; ++a)
+        for (int s_ = 0; s_ < SLABS; ++s_) {
+            if (s_ + PF < SLABS) load_slab(s_ + PF);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int b = 0; b < NT; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][e], bf[b][e], acc[a][b], 0, 0, 0);
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s_][a], bf[s_][b], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (more) {
-            la.commit((t & 1) ? sA0 : sA1, tid);
-            lb.commit((t & 1) ? sB0 : sB1, tid);
+            la.commit(nA, tid);
+            lb.commit(nB, tid);
         }
         __syncthreads();
     }
@@ -395,26 +432,31 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
 template <class AADDR, class BADDR, int BK, int VEC>
 int launch_rows_cols(const typename AADDR::P& pa, const typename BADDR::P& pb, const ConvG& cg, const Dims& d,
                      const Epi& ep, int chunks, hipStream_t st) {
-    const int Mg = d.Mg;
-    const long colTiles128 = ceil_div(d.Ng, 128);
-    const long z = (long)chunks * d.groups;
-    // candidate row tiles (BM) with 4 waves along columns: 32, 64, 96, 128(2x2 waves)
-    const int mt32 = ceil_div(Mg, 32);
-    // waste-free preference: largest of {3,2,1} x 32 dividing the padded row count
-    int MTsel = 1;
-    if (mt32 % 3 == 0) MTsel = 3; else if (mt32 % 2 == 0) MTsel = 2;
-    // if the grid would be too small, use the 32-row tile
-    const long blocks_big = (long)ceil_div(Mg, 32 * MTsel) * ceil_div(d.Ng, 256) * z;
-    if (blocks_big < 2L * num_cus()) {
-        const long blocks_mid = (long)ceil_div(Mg, 32 * MTsel) * colTiles128 * z;
-        if (blocks_mid < 2L * num_cus() || MTsel == 1)
-            return launch_cfg<AADDR, BADDR, 1, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
-        if (MTsel == 3) return launch_cfg<AADDR, BADDR, 3, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
-        return launch_cfg<AADDR, BADDR, 2, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+    // tuning knob (benchmarks only): MC_IGEMM_TILE="MT,NT" forces the wave tile
+    static const char* forced = getenv("MC_IGEMM_TILE");
+    if (forced && forced[0] && forced[1] == ',') {
+        const int fm = forced[0] - '0', fn = forced[2] - '0';
+#define MC_FORCE(a, b) if (fm == a && fn == b) return launch_cfg<AADDR, BADDR, a, b, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+        MC_FORCE(1, 1) MC_FORCE(2, 1) MC_FORCE(3, 1)
+#undef MC_FORCE
+        if (fm == 2 && fn == 3) return launch_cfg<AADDR, BADDR, 2, 3, 2, 2, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
     }
-    if (MTsel == 3) return launch_cfg<AADDR, BADDR, 3, 2, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
-    if (MTsel == 2) return launch_cfg<AADDR, BADDR, 2, 2, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
-    return launch_cfg<AADDR, BADDR, 1, 2, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+    // Measured on MI355X (tools/igemm_sweep.py): 128-column tiles (one 32-column strip per wave) beat
+    // 256-column tiles on every shape of the BASELINE nets; 192-column tiles (2x2 waves, 3 strips each)
+    // are used when they cut the padding of the column extent (F = 192 weight gradients: 256 -> 192).
+    const long z = (long)chunks * d.groups;
+    const int mt32 = ceil_div(d.Mg, 32);
+    const long pad128 = (long)ceil_div(d.Ng, 128) * 128, pad192 = (long)ceil_div(d.Ng, 192) * 192;
+    if (pad192 < pad128 && mt32 >= 4 && (long)ceil_div(d.Mg, 128) * ceil_div(d.Ng, 192) * z >= num_cus())
+        return launch_cfg<AADDR, BADDR, 2, 3, 2, 2, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+    // rows: the largest of {96, 64, 32} that divides the 32-padded row count, shrunk while the grid
+    // would leave CUs idle
+    int MTsel = (mt32 % 3 == 0) ? 3 : (mt32 % 2 == 0 || mt32 >= 8) ? 2 : 1;
+    const long colTiles = ceil_div(d.Ng, 128);
+    while (MTsel > 1 && (long)ceil_div(d.Mg, 32 * MTsel) * colTiles * z < num_cus()) --MTsel;
+    if (MTsel == 3) return launch_cfg<AADDR, BADDR, 3, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+    if (MTsel == 2) return launch_cfg<AADDR, BADDR, 2, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+    return launch_cfg<AADDR, BADDR, 1, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
 }
 
 inline float finv(int d) { return 1.0f / (float)d; }
@@ -454,8 +496,8 @@ int conv_filter_acts_impl(const float* images, const float* filters, float* targ
     MatP pa{filters, F, cg.fpg, cg.fpg};  // filters[k*F + g*fpg + f]
     ConvP pb{images, cg.M * N};
     const bool vec = (N % 4 == 0) && (cg.fpg % 4 == 0) && (F % 4 == 0) && aligned16(images) && aligned16(filters);
-    if (vec) return launch_rows_cols<MatNatAddr, PatchNatAddr, 16, 4>(pa, pb, cg, d, ep, 1, st);
-    return launch_rows_cols<MatNatAddr, PatchNatAddr, 16, 1>(pa, pb, cg, d, ep, 1, st);
+    if (vec) return launch_rows_cols<MatNatAddr, PatchNatAddr, MC_BK, 4>(pa, pb, cg, d, ep, 1, st);
+    return launch_rows_cols<MatNatAddr, PatchNatAddr, MC_BK, 1>(pa, pb, cg, d, ep, 1, st);
 }
 
 // =================================================================================
@@ -473,8 +515,8 @@ int conv_img_acts_impl(const float* hidActs, const float* filters, float* target
     ConvP pb{hidActs, H * W * N};
     // group offset of the A operand rows: channel c of group g uses filter rows (cl*fp+p), columns g*fpg+fl
     const bool vec = (N % 4 == 0) && (cg.fpg % 4 == 0) && (F % 4 == 0) && aligned16(hidActs) && aligned16(filters);
-    if (vec) return launch_rows_cols<FiltTAddr, HidNatAddr, 16, 4>(pa, pb, cg, d, ep, 1, st);
-    return launch_rows_cols<FiltTAddr, HidNatAddr, 16, 1>(pa, pb, cg, d, ep, 1, st);
+    if (vec) return launch_rows_cols<FiltTAddr, HidNatAddr, MC_BK, 4>(pa, pb, cg, d, ep, 1, st);
+    return launch_rows_cols<FiltTAddr, HidNatAddr, MC_BK, 1>(pa, pb, cg, d, ep, 1, st);
 }
 
 // =================================================================================
@@ -521,8 +563,8 @@ int gemm_impl(const float* A, const float* B, float* Cm, int m, int n, int k, in
     const bool vb = transB ? (k % 4 == 0) : (n % 4 == 0);
     const bool vec = al && va && vb;
 #define MC_GEMM_CASE(AA, BB)                                                              \
-    (vec ? launch_rows_cols<AA, BB, 16, 4>(pa, pb, cg, d, ep, chunks, st)                 \
-         : launch_rows_cols<AA, BB, 16, 1>(pa, pb, cg, d, ep, chunks, st))
+    (vec ? launch_rows_cols<AA, BB, MC_BK, 4>(pa, pb, cg, d, ep, chunks, st)                 \
+         : launch_rows_cols<AA, BB, MC_BK, 1>(pa, pb, cg, d, ep, chunks, st))
     if (transA && !transB) return MC_GEMM_CASE(MatNatAddr, MatNatAddr);
     if (!transA && !transB) return MC_GEMM_CASE(MatKcAddr, MatNatAddr);
     if (!transA && transB) return MC_GEMM_CASE(MatKcAddr, MatKcAddr);

@@ -355,6 +355,7 @@ void ConvNet::copyToGPU() {
         for (int i = 0; wl && i < wl->getNumWeights(); i++) _sharedWeights |= !wl->getWeights(i).isOwner();
     }
     for (Layer* l : _layers) l->copyToGPU();
+    buildUpdateSpans();
     RT_HIP(hipDeviceSynchronize());
 }
 
@@ -433,7 +434,37 @@ void ConvNet::flushBuckets(bool force) {
     }
 }
 
+// One launch updates every tensor (spans of <= 4096 elements, built once); tensors that do not
+// learn (eps == 0) have no spans, exactly as Weights::update skips them.
+void ConvNet::buildUpdateSpans() {
+    std::vector<mcUpdateSpan> spans;
+    for (Weights* w : _allWeights) {
+        if (w->getEps() <= 0) continue;
+        const float wceps = w->getWC() > 0 ? -w->getWC() * w->getEps() : 0.f;
+        for (size_t done = 0; done < w->numel(); done += 4096) {
+            mcUpdateSpan sp;
+            sp.start = w->arenaOffset() + done;
+            sp.count = (unsigned)std::min<size_t>(4096, w->numel() - done);
+            sp.mom = w->getMom();
+            sp.wceps = wceps;
+            sp.pad = 0;
+            spans.push_back(sp);
+        }
+    }
+    _numSpans = (int)spans.size();
+    if (_numSpans) {
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&_spans), spans.size() * sizeof(mcUpdateSpan)));
+        RT_HIP(hipMemcpy(_spans, spans.data(), spans.size() * sizeof(mcUpdateSpan), hipMemcpyHostToDevice));
+    }
+}
+
 void ConvNet::updateWeights() {
+    if (_numSpans) {
+        profileSetLayer("net");
+        RT_MC(mc_weights_update_spans(_arenaW, _arenaInc, _arenaGrad, _spans, _numSpans, reinterpret_cast<mcStream_t>(_stream)));
+        for (Weights* w : _allWeights) w->markUpdated();
+        return;
+    }
     for (Layer* l : _layers) l->updateWeights();
 }
 

@@ -169,6 +169,7 @@ private:
     void initDevice();
     Layer* initLayer(const std::string& layerType, PyObject* paramsDict);
     void flushBuckets(bool force);
+    void buildUpdateSpans();
 
     std::vector<Layer*> _layers;
     std::vector<DataLayer*> _dataLayers;
@@ -185,6 +186,8 @@ private:
     float *_arenaW = nullptr, *_arenaInc = nullptr, *_arenaGrad = nullptr;
     size_t _arenaElems = 0;
     size_t _bucketLo = 0, _bucketHi = 0;   // [lo, hi) of gradient elements ready but not yet reduced
+    mcUpdateSpan* _spans = nullptr;
+    int _numSpans = 0;
     float* _workspace = nullptr;
     size_t _workspaceBytes = 0;
     GradComm _comm;

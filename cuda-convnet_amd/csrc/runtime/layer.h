@@ -83,6 +83,7 @@ public:
     void copyToGPU();    // owner only; no-op for shared
     void copyToCPU();
     void update();       // weights.cuh:150-164, one fused kernel
+    void markUpdated() { _numUpdates = 0; }   // the net-wide single-launch update did this tensor
     // grad-check support: element (i, j) of the logical matrix <-> device offset
     size_t deviceIndex(int i, int j) const { return deviceFortran() ? (size_t)j * getNumRows() + i : (size_t)i * getNumCols() + j; }
     void releaseHost();  // GIL required

@@ -217,6 +217,21 @@ int mc_compute_logreg_softmax_grad(const float* labels, const float* probs, floa
 int mc_weights_update(float* weights, float* inc, const float* grad, size_t n, float mom, float eps,
                       float wc, mcStream_t stream);
 
+/* The same update for every tensor of a net in ONE launch: weights / inc / grad are the three
+ * arenas the tensors live in (same offsets in each), `spansDevice` a device array of spans; a span
+ * lies inside one tensor, starts 16-byte aligned, holds at most a few thousand elements and carries
+ * that tensor's momentum and wceps = (wc > 0 ? -wc*eps : 0).  One workgroup per span.
+ * No counterpart in the reference, which launches 2-3 element-wise kernels per tensor
+ * (Weights::update, weights.cuh:150-164). */
+typedef struct {
+    unsigned long long start; /* element offset into the arenas */
+    unsigned count;           /* elements in this span */
+    float mom, wceps;
+    unsigned pad;
+} mcUpdateSpan;
+int mc_weights_update_spans(float* weights, float* inc, const float* grad, const mcUpdateSpan* spansDevice,
+                            int numSpans, mcStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -279,7 +279,7 @@ def test_dropout_and_rng():
 def test_bias_and_reductions():
     m = mc()
     rng = np.random.default_rng(20)
-    for rows, cols in ((192, 16 * 16 * 128), (10, 64 * 16), (7, 33)):
+    for rows, cols in ((192, 16 * 16 * 128), (10, 64 * 16), (7, 33), (256, 75 * 192), (33, 20)):
         a = rng.standard_normal((rows, cols)).astype(np.float32)
         b = rng.standard_normal(rows).astype(np.float32)
         da = dev(a)
@@ -352,3 +352,37 @@ def test_rejected_calls_report():
         m.call("mc_conv_weight_acts", ptr(x), ptr(x), ptr(x), 4, 1, 2, 2, 1, 1, 0, 1, 2, 2, 1, 3, 0.0, 1.0, None)
     with pytest.raises(m.McError, match="paddingStart"):
         m.call("mc_conv_filter_acts", ptr(x), ptr(x), ptr(x), 4, 1, 2, 2, 1, 1, 1, 1, 2, 2, 1, 0.0, 1.0, None)
+
+
+def test_weights_update_spans_matches_per_tensor_update():
+    """One launch over the arenas == Weights::update per tensor (weights.cuh:150-164); padding between
+    tensors and tensors without spans (eps == 0) are left untouched."""
+    import ctypes
+    import torch
+    m = mc()
+    rng = np.random.default_rng(23)
+    sizes = [(75 * 192, 0.9, 0.001, 0.004), (192, 0.9, 0.002, 0.0), (5000, 0.0, 0.1, 0.0), (37, 0.5, 0.0, 0.0), (192 * 160, 0.9, 1.0, 1e-5)]
+    offs, total = [], 0
+    for n, *_ in sizes:
+        offs.append(total)
+        total += (n + 63) // 64 * 64
+    w, inc, grad = (rng.standard_normal(total).astype(np.float32) for _ in range(3))
+    ew, ei = w.copy(), inc.copy()
+
+    class Span(ctypes.Structure):
+        _fields_ = [("start", ctypes.c_ulonglong), ("count", ctypes.c_uint), ("mom", ctypes.c_float), ("wceps", ctypes.c_float), ("pad", ctypes.c_uint)]
+    spans = []
+    for (n, mom, eps, wc), o in zip(sizes, offs):
+        if eps <= 0:
+            continue
+        G.sgd_update(ew[o:o + n], ei[o:o + n], grad[o:o + n], eps, wc, mom)
+        for d in range(0, n, 4096):
+            spans.append(Span(o + d, min(4096, n - d), mom, -wc * eps if wc > 0 else 0.0, 0))
+    arr = (Span * len(spans))(*spans)
+    dspans = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).cuda()
+    dw, di, dg = dev(w), dev(inc), dev(grad)
+    m.call("mc_weights_update_spans", ptr(dw), ptr(di), ptr(dg), dspans.data_ptr(), len(spans), None)
+    np.testing.assert_allclose(host(di), ei, rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(host(dw), ew, rtol=2e-6, atol=1e-6)
+    o, n = offs[3], sizes[3][0]
+    assert np.array_equal(host(dw)[o:o + 64], w[o:o + 64]) and np.array_equal(host(di)[o:o + 64], inc[o:o + 64])
