@@ -72,7 +72,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    libkernel.setProfile("conv2:mc_conv_filter_acts_fused")
+    libkernel.setProfile("conv2/fwd:mc_conv_filter_acts_fused")
     barrier()
     t0 = time.perf_counter()
     libkernel.startResident(0, a.warmup % nres, a.steps)
@@ -103,7 +103,7 @@ def main():
         with open(a.kernel_table, "w") as f:
             json.dump([{"kernel": k, "launches_per_step": n / 10.0, "avg_ms": ms} for k, n, ms in rows], f, indent=1)
 
-    n_launch, total_ms = prof.get("conv2:mc_conv_filter_acts_fused", (0, 0.0))
+    n_launch, total_ms = prof.get("conv2/fwd:mc_conv_filter_acts_fused", (0, 0.0))
     avg_ms = total_ms / max(n_launch, 1)
     achieved = CONV2_FLOPS / (avg_ms * 1e-3) / 1e12 if n_launch else None
     out = {

@@ -58,6 +58,45 @@ __global__ void k_splitk_reduce(const float* __restrict__ slabs, float* C, int m
     }
 }
 
+// Same reduction for many slabs: workgroup = 16 float4 columns x 16 slab groups; thread (cg, qg) adds
+// slabs qg, qg+16, ... in order, then the 16 partials are added in a fixed LDS tree (deterministic).
+// Requires n % 4 == 0, ldc % 4 == 0 and 16-byte aligned pointers.
+__global__ void __launch_bounds__(256) k_splitk_reduce_tall(const float4* __restrict__ slabs, float* C, int m, int n4, int ldc, int chunks,
+                                                              float alpha, float beta, const float* __restrict__ bias, int act) {
+    __shared__ float4 sh[16][17];
+    const int cg = threadIdx.x & 15, qg = threadIdx.x >> 4;
+    const size_t total4 = (size_t)m * n4;
+    const size_t e = (size_t)blockIdx.x * 16 + cg;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < total4)
+        for (int q = qg; q < chunks; q += 16) {
+            const float4 x = slabs[(size_t)q * total4 + e];
+            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        }
+    sh[qg][cg] = acc;
+    __syncthreads();
+    for (int half = 8; half > 0; half >>= 1) {
+        if (qg < half) {
+            const float4 a = sh[qg][cg], b = sh[qg + half][cg];
+            sh[qg][cg] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        }
+        __syncthreads();
+    }
+    if (qg == 0 && e < total4) {
+        const float4 t = sh[0][cg];
+        const int i = (int)(e / n4), j4 = (int)(e - (size_t)i * n4);
+        float4* dst = reinterpret_cast<float4*>(C + (size_t)i * ldc) + j4;
+        float4 v = make_float4(alpha * t.x, alpha * t.y, alpha * t.z, alpha * t.w);
+        if (beta != 0.f) {
+            const float4 o = *dst;
+            v.x += beta * o.x; v.y += beta * o.y; v.z += beta * o.z; v.w += beta * o.w;
+        }
+        if (bias) { const float b = bias[i]; v.x += b; v.y += b; v.z += b; v.w += b; }
+        if (act == MC_NEURON_RELU) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }
+        *dst = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // Unshared (local) layers: per-module filter banks W[m][c][p][f]
 // (Kernel/src/conv/filter_acts.cu:100-102 with conv=false).  Weight-bandwidth bound and
@@ -163,12 +202,15 @@ inline int grid_items(size_t items) {
 }
 
 int pick_gemm_chunks(int m, int n, int k) {
-    const long tiles = (long)ceil_div(m, 32) * ceil_div(n, 128);
+    // tiles of the shape launch_rows_cols will pick for a long-k product: 128 x 192 when that pads the
+    // column extent less, else 96 x 128
+    const bool wide = (long)ceil_div(n, 192) * 192 < (long)ceil_div(n, 128) * 128 && m > 96;
+    const long tiles = wide ? (long)ceil_div(m, 128) * ceil_div(n, 192) : (long)ceil_div(m, 96) * ceil_div(n, 128);
     if (k < 2048 || tiles >= num_cus()) return 1;
     long want = (2L * num_cus() + tiles - 1) / tiles;
-    const long maxc = k / 512;
+    const long maxc = k / 256;   // at least 256 k per chunk (8-16 LDS tiles)
     if (want > maxc) want = maxc;
-    if (want > 64) want = 64;
+    if (want > 128) want = 128;
     return want < 1 ? 1 : (int)want;
 }
 
@@ -320,8 +362,12 @@ int mc_gemm(const float* A, const float* B, float* C, int m, int n, int k, int t
         // gemm_impl may round the chunk size up; recompute how many slabs were written
         int kChunk = (ceil_div(k, chunks) + 31) / 32 * 32;
         const int written = ceil_div(k, kChunk);
-        hipLaunchKernelGGL(k_splitk_reduce, dim3(grid_items((size_t)m * n)), dim3(TPB), 0, S(s), slabs, C, m, n, ldc,
-                           written, scaleOutput, scaleTargets, rowBias, neuron);
+        if (n % 4 == 0 && ldc % 4 == 0 && aligned16(C) && written >= 16)
+            hipLaunchKernelGGL(k_splitk_reduce_tall, dim3(ceil_div((long)m * (n / 4), 16)), dim3(256), 0, S(s),
+                               reinterpret_cast<const float4*>(slabs), C, m, n / 4, ldc, written, scaleOutput, scaleTargets, rowBias, neuron);
+        else
+            hipLaunchKernelGGL(k_splitk_reduce, dim3(grid_items((size_t)m * n)), dim3(TPB), 0, S(s), slabs, C, m, n, ldc,
+                               written, scaleOutput, scaleTargets, rowBias, neuron);
         return launch_status("mc_gemm(split-k reduce)");
     }
     return gemm_impl(A, B, C, m, n, k, transA, transB, lda, ldb, ldc, scaleTargets, scaleOutput, rowBias, neuron, 1, 0,

@@ -437,7 +437,7 @@ int launch_rows_cols(const typename AADDR::P& pa, const typename BADDR::P& pb, c
     if (forced && forced[0] && forced[1] == ',') {
         const int fm = forced[0] - '0', fn = forced[2] - '0';
 #define MC_FORCE(a, b) if (fm == a && fn == b) return launch_cfg<AADDR, BADDR, a, b, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
-        MC_FORCE(1, 1) MC_FORCE(2, 1) MC_FORCE(3, 1)
+        MC_FORCE(1, 1) MC_FORCE(2, 1) MC_FORCE(3, 1) MC_FORCE(5, 1)
 #undef MC_FORCE
         if (fm == 2 && fn == 3) return launch_cfg<AADDR, BADDR, 2, 3, 2, 2, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
     }
@@ -451,8 +451,11 @@ int launch_rows_cols(const typename AADDR::P& pa, const typename BADDR::P& pb, c
         return launch_cfg<AADDR, BADDR, 2, 3, 2, 2, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
     // rows: the largest of {96, 64, 32} that divides the 32-padded row count, shrunk while the grid
     // would leave CUs idle
-    int MTsel = (mt32 % 3 == 0) ? 3 : (mt32 % 2 == 0 || mt32 >= 8) ? 2 : 1;
     const long colTiles = ceil_div(d.Ng, 128);
+    // exactly 160 rows (NIN cccp1 / cccp2): one 160-row tile reads the big operand once
+    if (mt32 == 5 && colTiles * z >= 2L * num_cus())
+        return launch_cfg<AADDR, BADDR, 5, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+    int MTsel = (mt32 % 3 == 0) ? 3 : (mt32 % 2 == 0 || mt32 >= 8) ? 2 : 1;
     while (MTsel > 1 && (long)ceil_div(d.Mg, 32 * MTsel) * colTiles * z < num_cus()) --MTsel;
     if (MTsel == 3) return launch_cfg<AADDR, BADDR, 3, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
     if (MTsel == 2) return launch_cfg<AADDR, BADDR, 2, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
@@ -567,7 +570,9 @@ int gemm_impl(const float* A, const float* B, float* Cm, int m, int n, int k, in
          : launch_rows_cols<AA, BB, MC_BK, 1>(pa, pb, cg, d, ep, chunks, st))
     if (transA && !transB) return MC_GEMM_CASE(MatNatAddr, MatNatAddr);
     if (!transA && !transB) return MC_GEMM_CASE(MatKcAddr, MatNatAddr);
-    if (!transA && transB) return MC_GEMM_CASE(MatKcAddr, MatKcAddr);
+    if (!transA && transB)
+        return vec ? launch_rows_cols<MatKcAddr, MatKcAddr, 32, 4>(pa, pb, cg, d, ep, chunks, st)
+                   : launch_rows_cols<MatKcAddr, MatKcAddr, 32, 1>(pa, pb, cg, d, ep, chunks, st);
     return MC_GEMM_CASE(MatNatAddr, MatKcAddr);
 #undef MC_GEMM_CASE
 }

@@ -461,6 +461,7 @@ void ConvNet::buildUpdateSpans() {
 void ConvNet::updateWeights() {
     if (_numSpans) {
         profileSetLayer("net");
+        profileSetPhase("update");
         RT_MC(mc_weights_update_spans(_arenaW, _arenaInc, _arenaGrad, _spans, _numSpans, reinterpret_cast<mcStream_t>(_stream)));
         for (Weights* w : _allWeights) w->markUpdated();
         return;

@@ -23,7 +23,7 @@ void setComputeStream(hipStream_t s) { t_stream = s; }
 namespace {
 struct ProfRec { std::string key; hipEvent_t a, b; };
 std::vector<ProfRec> g_prof;
-std::string g_profFilter, g_profLayer;
+std::string g_profFilter, g_profLayer, g_profPhase;
 bool g_profOn = false;
 }  // namespace
 
@@ -36,10 +36,14 @@ void profileSetLayer(const char* layerName) {
     if (g_profOn) g_profLayer = layerName ? layerName : "";
 }
 
+void profileSetPhase(const char* phase) {
+    if (g_profOn) g_profPhase = phase ? phase : "";
+}
+
 ProfScope::ProfScope(const char* callText) {
     if (!g_profOn) return;
     const char* paren = strchr(callText, '(');
-    std::string key = g_profLayer + ":" + std::string(callText, paren ? (size_t)(paren - callText) : strlen(callText));
+    std::string key = g_profLayer + (g_profPhase.empty() ? "" : "/" + g_profPhase) + ":" + std::string(callText, paren ? (size_t)(paren - callText) : strlen(callText));
     if (g_profFilter != "*" && key.find(g_profFilter) == std::string::npos) return;
     ProfRec r;
     r.key = key;

@@ -41,6 +41,7 @@ private:
 };
 void profileSetFilter(const char* filter);            // NULL / "" switches profiling off
 void profileSetLayer(const char* layerName);
+void profileSetPhase(const char* phase);              // "fwd" / "wgrad" / "bwd": part of the key
 void profileReport(std::map<std::string, std::pair<long, double>>& out, bool reset);
 
 // Every kernel call of the runtime goes through this: a rejected call is a bug in the caller's

@@ -61,6 +61,7 @@ void Layer::fprop(DevMatV& v, PASS_TYPE passType) {
     if (_actsTarget < 0 && _numOutputs > 0) _ownOutputs.resize(_numOutputs, _numCases);
 
     profileSetLayer(_name.c_str());
+    profileSetPhase("fwd");
     // the input whose matrix this layer writes into goes first, the others accumulate
     if (_actsTarget >= 0) fpropActs(_actsTarget, 0, passType);
     for (int i = 0; i < (int)_prev.size(); i++)
@@ -77,7 +78,9 @@ void Layer::bprop(PASS_TYPE passType) {
 
 void Layer::bprop(DevMat& v, PASS_TYPE passType) {
     profileSetLayer(_name.c_str());
+    profileSetPhase("wgrad");
     bpropCommon(v, passType);
+    profileSetPhase("bwd");
     if (isGradProducer()) {
         auto send = [&](int i) {
             Layer* p = _prev[i];
@@ -87,6 +90,7 @@ void Layer::bprop(DevMat& v, PASS_TYPE passType) {
                 if (accumulate) throw std::runtime_error(fmt("layer '%s': gradient of '%s' changed shape while accumulating", _name.c_str(), p->getName().c_str()));
                 tgt.resize(p->getNumOutputs(), _numCases);
             }
+            profileSetLayer(_name.c_str());
             bpropActs(v, i, accumulate ? 1.f : 0.f, passType);
             p->incRcvdBInputs();
         };

@@ -38,12 +38,16 @@ def conv(name, C, H, fs, F, pad, which="fbw"):
         print("%-6s %-28s bwd-wts(ps=%d) %8.3f ms %7.1f TF/s" % (tile, name, ps, ms, fl/ms/1e9))
 def gemm(mm, nn, kk, ta=0, tb=0):
     A = R(kk, mm) if ta else R(mm, kk); B = R(nn, kk) if tb else R(kk, nn); C = torch.empty(mm, nn, device="cuda")
-    ms = t_ms(lambda: m.call("mc_gemm", P(A), P(B), P(C), mm, nn, kk, ta, tb, A.shape[1], B.shape[1], nn, 0.0, 1.0, None, 0, None, 0, None))
+    wsb = m.lib().mc_gemm_workspace_bytes(mm, nn, kk); ws = torch.empty(max(1, wsb // 4), device="cuda")
+    ms = t_ms(lambda: m.call("mc_gemm", P(A), P(B), P(C), mm, nn, kk, ta, tb, A.shape[1], B.shape[1], nn, 0.0, 1.0, None, 0, P(ws), wsb, None))
     print("%-6s gemm %dx%dx%d ta=%d tb=%d %8.3f ms %7.1f TF/s" % (tile, mm, nn, kk, ta, tb, ms, 2.0*mm*nn*kk/ms/1e9))
 if what in ("all", "conv2"): conv("conv2 96->192 5x5 16^2", 96, 16, 5, 192, 2)
 if what in ("all", "conv2f"): conv("conv2 96->192 5x5 16^2", 96, 16, 5, 192, 2, "f")
 if what in ("all", "gemm"):
     gemm(4096, 4096, 4096, 1, 0); gemm(4096, 4096, 4096, 0, 0)
     gemm(160, 131072, 192, 0, 0); gemm(192, 131072, 160, 1, 0)
+if what in ("all", "cccp"):
+    for (i, o, pp) in ((192, 160, 1024), (160, 96, 1024), (192, 192, 256), (192, 192, 64), (192, 10, 64)):
+        gemm(o, pp * N, i, 0, 0); gemm(i, pp * N, o, 1, 0); gemm(o, i, pp * N, 0, 1)
 if what in ("all", "conv13"):
     conv("conv1 3->192 5x5 32^2", 3, 32, 5, 192, 2, "fw"); conv("conv3 192->192 3x3 8^2", 192, 8, 3, 192, 1)
