@@ -28,6 +28,7 @@ NET = "nin"
 FP32_MFMA_PEAK = 157.3e12       # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 CONV2_FLOPS = 2.0 * 2400 * 192 * 256 * MB     # 2 * K * F * modules * images
 TRAIN_GFLOP_PER_STEP = 167.09
+CONV2_BYTES = 4 * ((96 * 256 + 192 * 256) * MB + 2400 * 192)   # input + output + filters, each touched once
 
 
 def main():
@@ -103,6 +104,15 @@ def main():
         with open(a.kernel_table, "w") as f:
             json.dump([{"kernel": k, "launches_per_step": n / 10.0, "avg_ms": ms} for k, n, ms in rows], f, indent=1)
 
+    # HBM traffic of the same launch: PMC counters cannot be read from inside this process, so the
+    # value is the one measured by the separate rocprofv3 --pmc passes (tools/profile_round.sh) and
+    # committed under profiles/ together with the counter summaries it comes from.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            traffic = json.load(f)["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     n_launch, total_ms = prof.get("conv2/fwd:mc_conv_filter_acts_fused", (0, 0.0))
     avg_ms = total_ms / max(n_launch, 1)
     achieved = CONV2_FLOPS / (avg_ms * 1e-3) / 1e12 if n_launch else None
@@ -117,7 +127,8 @@ def main():
                    "logprob_per_case": costs["logprob"][0] / max(ncases, 1)},
         "roofline": {"bound": "mfma", "kernel": "conv2 forward (mc_igemm, implicit GEMM 192 x 32768 x 2400)", "achieved": achieved,
                      "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": (achieved / (FP32_MFMA_PEAK / 1e12)) if achieved else None,
-                     "traffic": None, "avg_launch_ms": avg_ms, "launches_timed": n_launch},
+                     "traffic": traffic, "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/pmc_traffic.json)",
+                     "algorithmic_bytes": CONV2_BYTES, "avg_launch_ms": avg_ms, "launches_timed": n_launch},
     }
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(modelutil)

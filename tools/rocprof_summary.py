@@ -1,5 +1,9 @@
-"""Turns a rocprofv3 (rocpd sqlite) result into the text kernel-stats summary kept under profiles/:
-   python tools/rocprof_summary.py gpurun_out/prof_r01/nin_results.db profiles/r01_....txt "command line" """
+"""Turns a rocprofv3 --kernel-trace --stats result (rocpd sqlite) into the text summary kept under profiles/:
+   python tools/rocprof_summary.py gpurun_out/prof_r01/trace/nin_results.db profiles/r01_....txt "command line"
+Part 1 is rocprofv3's own per-kernel statistics (top_kernels).  Part 2 splits every kernel by launch
+shape (grid in workgroups), because one mc_igemm instantiation serves several layers: NIN's conv2
+forward is mc_igemm<MatNatAddr, PatchNatAddr, ...> with grid (256,2,1) -- the launch bench.py's
+`roofline` object times."""
 import re
 import sqlite3
 import sys
@@ -20,4 +24,10 @@ with open(out, "w") as f:
     f.write("%-100s %8s %14s %12s %7s\n" % ("kernel", "calls", "total_us", "avg_us", "pct"))
     for name, calls, total, avg, pct in rows:
         f.write("%-100s %8d %14.1f %12.3f %6.2f%%\n" % (short(name)[:100], calls, total, avg, pct))
-print(open(out).read()[:3000])
+    f.write("\n# the same trace split by launch shape (grid in workgroups); registers and LDS per workgroup\n")
+    f.write("%-72s %-16s %6s %12s %12s %5s %7s\n" % ("kernel", "grid", "calls", "avg_us", "total_us", "vgpr", "lds"))
+    q = ("select name, grid_x / workgroup_x, grid_y / workgroup_y, grid_z / workgroup_z, count(*), avg(duration) / 1e3, "
+         "sum(duration) / 1e3, max(vgpr_count), max(lds_size) from kernels group by name, grid_x, grid_y, grid_z order by 7 desc")
+    for name, gx, gy, gz, calls, avg, total, vgpr, lds in cur.execute(q):
+        f.write("%-72s %-16s %6d %12.3f %12.1f %5d %7d\n" % (short(name)[:72], "(%d,%d,%d)" % (gx, gy, gz), calls, avg, total, vgpr, lds))
+print(open(out).read()[:6000])
