@@ -350,9 +350,9 @@ int mc_gemm(const float* A, const float* B, float* C, int m, int n, int k, int t
     MC_REQUIRE(m > 0 && n > 0 && k > 0, "mc_gemm: non-positive dimension (%d,%d,%d)", m, n, k);
     MC_REQUIRE(lda >= (transA ? m : k) && ldb >= (transB ? k : n) && ldc >= n, "mc_gemm: leading dimension too small");
     MC_REQUIRE(neuron == MC_NEURON_NONE || neuron == MC_NEURON_RELU, "mc_gemm: unknown neuron %d", neuron);
-    MC_REQUIRE((size_t)(transA ? k : m) * lda < (1ull << 31) && (size_t)(transB ? n : k) * ldb < (1ull << 31) &&
+    MC_REQUIRE((size_t)(transA ? k : m) * lda < (1ull << 30) && (size_t)(transB ? n : k) * ldb < (1ull << 30) &&
                    (size_t)m * ldc < (1ull << 31),
-               "mc_gemm: operand exceeds 32-bit indexing");
+               "mc_gemm: operand exceeds the 4 GiB buffer-descriptor range");
     int chunks = pick_gemm_chunks(m, n, k);
     if (chunks > 1 && workspace && workspaceBytes >= (size_t)chunks * m * n * sizeof(float) && aligned16(workspace)) {
         float* slabs = static_cast<float*>(workspace);

@@ -18,8 +18,12 @@
 //       KC   [BK/4][ROWS+1][4] operand is contiguous along k -> one ds_read_b128 feeds 4 MFMAs.
 //     Any k permutation is legal as long as A and B agree, so inside each group of 8 k's
 //     MFMA e (0..3) of lane-half h consumes k = 4h + e; that makes both layouts line up.
-//   * global -> registers -> LDS double buffering, one barrier per K step; the next tile's
-//     global loads are issued before the MFMAs of the current one.
+//   * Wave specialisation: a workgroup is 8 waves = 4 consumer waves (LDS fragment reads + MFMA only,
+//     one per SIMD) and 4 producer waves (tile gather: address arithmetic, buffer loads with
+//     out-of-range -> 0 predication, LDS stores).  The matrix pipe and the vector/memory pipes are
+//     separate, so the producers' work runs under the consumers' MFMAs instead of in front of them.
+//     Producers keep two register sets: tile t+2's loads are issued before tile t+1 is written to
+//     the idle LDS buffer, so a load has up to two K steps to land.  One barrier per K step.
 //   * blockIdx.z = (k-chunk q, group g): k-chunks give deterministic split-K (each chunk writes
 //     its own slab; the reference's partialSum layout is exactly that), groups are independent
 //     GEMMs on disjoint channel/filter ranges.
@@ -32,6 +36,9 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int THREADS = 256;
+#ifndef MC_NS
+#define MC_NS 3    // tile register sets per producer thread (tiles in flight per workgroup)
+#endif
 #ifndef MC_BK
 #define MC_BK 16   // k extent of one LDS tile for the contractions whose operands are not both k-contiguous
 #endif
@@ -51,6 +58,7 @@ struct Dims {
     int Mg, Ng, Kg;   // GEMM extents (per group)
     int kChunk;       // k extent of one chunk (multiple of 4 when a KC loader is vectorised)
     int groups;
+    int xcdSwizzle;   // set by launch_cfg when gridDim.x % 8 == 0
 };
 
 struct Epi {
@@ -75,6 +83,7 @@ struct MatP {
     int ld;      // row stride of the stored matrix
     int R;       // extent of the non-k axis (per group)
     int gStride; // offset added per group
+    unsigned bytes;  // extent of the whole operand (buffer descriptor range: loads beyond it return 0)
 };
 
 // stored (K, R): element (k, x) at k*ld + x
@@ -101,6 +110,7 @@ struct MatKcAddr {
 struct ConvP {
     const float* p;
     int R;  // extent of the non-k axis
+    unsigned bytes;  // extent of the whole tensor (buffer descriptor range)
 };
 
 // im2col patch element: filter tap kc = (c, fy, fx), column (m, n)
@@ -181,12 +191,21 @@ struct FiltTAddr {
 };
 
 // ---------------------------------------------------------------------------------
-// Tile loader: global -> registers (fetch) -> LDS (commit).
+// Tile loader (producer waves): global -> registers (fetch) -> LDS (commit).
 //   ADDR::KC == false: LDS [BK][ROWS] floats, chunk = 4 consecutive x at one k
 //   ADDR::KC == true : LDS [BK/4][ROWS+1] float4, chunk = 4 consecutive k at one x
-// VEC == 4: one predicated 16-byte load per chunk (caller guarantees alignment and that
-// a chunk never straddles a validity boundary); VEC == 1: four predicated scalar loads.
+// VEC == 4: one 16-byte buffer load per chunk (caller guarantees alignment and that a chunk never
+// straddles a validity boundary); VEC == 1: four 4-byte buffer loads.  Predication is branch-free:
+// an element that contributes 0 (padding tap, k tail, row/column tail) is loaded at offset
+// 0xFFFFFFFF, which the buffer descriptor's range check turns into a 0 without touching memory.
 // ---------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0xFFFFFFFFu;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
+}
+
 template <class ADDR, int ROWS, int BK, int VEC>
 struct Loader {
     typedef typename ADDR::P P;
@@ -208,49 +227,41 @@ struct Loader {
         }
     }
 
-    // one chunk ("piece" `it`) of the tile: address arithmetic + predicated global load
-    __device__ __forceinline__ void fetch_one(int it, const P& p, const ConvG& cg, int g, int k0, int kend, int x0, int tid) {
-        const float* base = ADDR::base(p);
-        const int c = tid + it * THREADS;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (CHUNKS % THREADS == 0 || c < CHUNKS) {
+    __device__ __forceinline__ void fetch(__amdgpu_buffer_rsrc_t rs, const P& p, const ConvG& cg, int g, int k0, int kend, int x0,
+                                          int tid) {
+#ifdef MC_ABL_NOFETCH   // timing-only ablation builds (tools/build_variant.sh); wrong results
+        if (k0 > 0) return;
+#endif
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) {
+            const int c = tid + it * THREADS;
+            const bool live = CHUNKS % THREADS == 0 || c < CHUNKS;
             int dk, dx;
             chunk_pos(c, dk, dx);
             const int k = k0 + dk, x = x0 + dx;
             if (VEC == 4) {
                 int off;
-                const bool ok = ADDR::addr(p, cg, g, k, x, off) & (k < kend);
-                if (ok) v = *reinterpret_cast<const float4*>(base + off);
+                const bool ok = ADDR::addr(p, cg, g, k, x, off) & (k < kend) & live;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)off * 4u : OOB, 0, 0);
+                r[it] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
             } else {
                 float e[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int ku = KC ? k + u : k, xu = KC ? x : x + u;
                     int off;
-                    const bool ok = ADDR::addr(p, cg, g, ku, xu, off) & (ku < kend);
-                    e[u] = ok ? base[off] : 0.f;
+                    const bool ok = ADDR::addr(p, cg, g, ku, xu, off) & (ku < kend) & live;
+                    e[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, ok ? (unsigned)off * 4u : OOB, 0, 0));
                 }
-                v = make_float4(e[0], e[1], e[2], e[3]);
+                r[it] = make_float4(e[0], e[1], e[2], e[3]);
             }
-        }
-        r[it] = v;
-    }
-
-    __device__ __forceinline__ void fetch(const P& p, const ConvG& cg, int g, int k0, int kend, int x0, int tid) {
-#pragma unroll
-        for (int it = 0; it < NCH; ++it) fetch_one(it, p, cg, g, k0, kend, x0, tid);
-    }
-
-    __device__ __forceinline__ void commit_one(int it, float* lds, int tid) const {
-        float4* l4 = reinterpret_cast<float4*>(lds);
-        const int c = tid + it * THREADS;
-        if (CHUNKS % THREADS == 0 || c < CHUNKS) {
-            if (KC) l4[(c % (BK / 4)) * ROWSP + c / (BK / 4)] = r[it];
-            else l4[c] = r[it];
         }
     }
 
     __device__ __forceinline__ void commit(float* lds, int tid) const {
+#ifdef MC_ABL_NOCOMMIT
+        return;
+#endif
         float4* l4 = reinterpret_cast<float4*>(lds);
 #pragma unroll
         for (int it = 0; it < NCH; ++it) {
@@ -266,13 +277,22 @@ struct Loader {
     }
 };
 
+// LDS stores of this wave have landed, then the workgroup barrier.  Deliberately NOT __syncthreads():
+// that also waits for vmcnt(0), which would drain the producers' in-flight tile loads at every K step.
+__device__ __forceinline__ void lds_done_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // ---------------------------------------------------------------------------------
-// The kernel.  256 threads = 4 waves laid out WM x WN; wave tile (32*MT) x (32*NT).
+// The kernel.  512 threads: waves 0-3 are consumers laid out WM x WN, wave tile (32*MT) x (32*NT);
+// waves 4-7 are producers (THREADS = 256 of them share the tile gather).
 // ---------------------------------------------------------------------------------
-template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC>
-__global__ void __launch_bounds__(THREADS)
+template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC, int NS>
+__global__ void __launch_bounds__(2 * THREADS)
 mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
-    static_assert(WM * WN == 4, "4 waves");
+    static_assert(WM * WN == 4, "4 consumer waves");
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     typedef Loader<AADDR, BM, BK, VEC> LA;
     typedef Loader<BADDR, BN, BK, VEC> LB;
@@ -282,15 +302,74 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     float* sB0 = smem + 2 * LA::LDS_FLOATS;
     float* sB1 = sB0 + LB::LDS_FLOATS;
 
+    // column-tile index: with d.xcdSwizzle the grid's x extent is a multiple of 8 and workgroups are dealt
+    // round-robin over the 8 XCDs, so workgroup b -> tile (b % 8) * (gridDim.x / 8) + b / 8 keeps
+    // neighbouring column tiles (neighbouring modules, overlapping patches) on one XCD's L2.
+    const int bx = d.xcdSwizzle ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int i0 = blockIdx.y * BM, j0 = bx * BN;
+    const int q = blockIdx.z / d.groups, g = blockIdx.z - q * d.groups;
+    const int kbeg = q * d.kChunk;
+    const int kend = min(kbeg + d.kChunk, d.Kg);
+    const int nk = (kend - kbeg + BK - 1) / BK;   // >= 1 K steps; barriers executed by every wave: 1 + nk
+
+    if (threadIdx.x >= THREADS) {
+        // ------------------------------ producer waves ------------------------------
+        // Register ring of NS tile sets: tile u lives in set u % NS.  During K step t the consumers read
+        // LDS buffer t & 1; the producers first issue tile t+NS's loads into the set that tile t left
+        // free, then write tile t+1 (the oldest loads in flight) to LDS buffer (t+1) & 1.  Up to NS tiles
+        // are in flight per workgroup: under load an L2 / Infinity-Cache read takes 1-2 us, several K steps.
+        const int tid = threadIdx.x - THREADS;
+        const __amdgpu_buffer_rsrc_t ra = make_rsrc(AADDR::base(pa), pa.bytes), rb = make_rsrc(BADDR::base(pb), pb.bytes);
+        LA as[NS];
+        LB bs[NS];
+#pragma unroll
+        for (int u = 0; u < NS; ++u)
+            if (u < nk) {
+                as[u].fetch(ra, pa, cg, g, kbeg + u * BK, kend, i0, tid);
+                bs[u].fetch(rb, pb, cg, g, kbeg + u * BK, kend, j0, tid);
+            }
+        as[0].commit(sA0, tid);
+        bs[0].commit(sB0, tid);
+        lds_done_barrier();   // tile 0 visible
+        int t = 0;
+        // steady state: NS K steps per trip, no conditionals inside (keeps the compiler's vmcnt counts exact)
+        for (; t + 2 * NS <= nk; t += NS) {
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                const int tt = t + j;
+                as[j].fetch(ra, pa, cg, g, kbeg + (tt + NS) * BK, kend, i0, tid);
+                bs[j].fetch(rb, pb, cg, g, kbeg + (tt + NS) * BK, kend, j0, tid);
+                as[(j + 1) % NS].commit(((tt + 1) & 1) ? sA1 : sA0, tid);
+                bs[(j + 1) % NS].commit(((tt + 1) & 1) ? sB1 : sB0, tid);
+                lds_done_barrier();   // end of K step tt
+            }
+        }
+        // tail: fewer than 2*NS K steps left; t is a multiple of NS, so the set indices stay static
+        for (; t < nk; t += NS) {
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                const int tt = t + j;
+                if (tt < nk) {
+                    if (tt + NS < nk) {
+                        as[j].fetch(ra, pa, cg, g, kbeg + (tt + NS) * BK, kend, i0, tid);
+                        bs[j].fetch(rb, pb, cg, g, kbeg + (tt + NS) * BK, kend, j0, tid);
+                    }
+                    if (tt + 1 < nk) {
+                        as[(j + 1) % NS].commit(((tt + 1) & 1) ? sA1 : sA0, tid);
+                        bs[(j + 1) % NS].commit(((tt + 1) & 1) ? sB1 : sB0, tid);
+                    }
+                    lds_done_barrier();   // end of K step tt
+                }
+            }
+        }
+        return;
+    }
+
+    // ------------------------------ consumer waves ------------------------------
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l31 = lane & 31;
     const int wm = wave / WN, wn = wave % WN;
-    const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
-    const int q = blockIdx.z / d.groups, g = blockIdx.z - q * d.groups;
-    const int kbeg = q * d.kChunk;
-    const int kend = min(kbeg + d.kChunk, d.Kg);
-    const int nk = (kend - kbeg + BK - 1) / BK;
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -300,25 +379,15 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    LA la;
-    LB lb;
-    la.fetch(pa, cg, g, kbeg, kend, i0, tid);
-    lb.fetch(pb, cg, g, kbeg, kend, j0, tid);
-    la.commit(sA0, tid);
-    lb.commit(sB0, tid);
-    __syncthreads();
+    lds_done_barrier();   // tile 0 visible
 
     for (int t = 0; t < nk; ++t) {
         const float* cA = (t & 1) ? sA1 : sA0;
         const float* cB = (t & 1) ? sB1 : sB0;
-        const bool more = t + 1 < nk;
-        float* nA = (t & 1) ? sA0 : sA1;
-        float* nB = (t & 1) ? sB0 : sB1;
-        const int knext = kbeg + (t + 1) * BK;
         // LDS -> register fragments, software-pipelined: "slab" s holds the operands of one MFMA
         // k-step (2 k values: lane half h supplies k = kof(s) + h-dependent offset).  The reads of
-        // slab s+PF are issued before the MFMAs of slab s, so the ~100-cycle LDS latency hides
-        // behind PF * MT*NT * 64 cycles of matrix work instead of stalling every other MFMA.
+        // slab s+PF are issued before the MFMAs of slab s, so the LDS latency hides behind
+        // PF * MT*NT * 64 cycles of matrix work instead of stalling every other MFMA.
         constexpr int SLABS = BK / 2, PF = 2;
         float af[SLABS][MT], bf[SLABS][NT];
         auto load_slab = [&](int s_) {
@@ -352,13 +421,6 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         };
 #pragma unroll
         for (int s_ = 0; s_ < PF; ++s_) load_slab(s_);
-        // Next tile: all global loads are issued before this tile's MFMAs and stored to the idle LDS
-        // buffer after them.  (Spreading the loads / stores between the slabs was measured: no gain for
-        // the forward kernel, -15 % for the weight-gradient kernel, whose loads then land too late.)
-        if (more) {
-            la.fetch(pa, cg, g, knext, kend, i0, tid);
-            lb.fetch(pb, cg, g, knext, kend, j0, tid);
-        }
 #pragma unroll
         for (int s_ = 0; s_ < SLABS; ++s_) {
             if (s_ + PF < SLABS) load_slab(s_ + PF);
@@ -370,11 +432,7 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s_][a], bf[s_][b], acc[a][b], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) {
-            la.commit(nA, tid);
-            lb.commit(nB, tid);
-        }
-        __syncthreads();
+        lds_done_barrier();   // end of K step t: every fragment read of this buffer has been consumed
     }
 
     // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -404,26 +462,29 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
 // ---------------------------------------------------------------------------------
 // Host-side launch helpers
 // ---------------------------------------------------------------------------------
-template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC>
-int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const ConvG& cg, const Dims& d,
+template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC, int NS = MC_NS>
+int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const ConvG& cg, const Dims& d0,
                const Epi& ep, int chunks, hipStream_t st) {
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     typedef Loader<AADDR, BM, BK, VEC> LA;
     typedef Loader<BADDR, BN, BK, VEC> LB;
     constexpr size_t lds = 2 * (LA::LDS_FLOATS + LB::LDS_FLOATS) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = mc_igemm<AADDR, BADDR, MT, NT, WM, WN, BK, VEC>;
+    auto kern = mc_igemm<AADDR, BADDR, MT, NT, WM, WN, BK, VEC, NS>;
+    Dims d = d0;
     static bool attr_done = false;
     if (lds > 48 * 1024 && !attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     dim3 grid(ceil_div(d.Ng, BN), ceil_div(d.Mg, BM), chunks * d.groups);
+    static const bool noswz = getenv("MC_IGEMM_NOSWZ") != nullptr;
+    d.xcdSwizzle = (grid.x % 8 == 0 && grid.x >= 16 && !noswz) ? 1 : 0;
     if (grid.y > 65535 || grid.z > 65535) {
         set_error("igemm: grid too large (%u,%u,%u)", grid.x, grid.y, grid.z);
         return MC_EINVAL;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(THREADS), lds, st, pa, pb, cg, d, ep);
+    hipLaunchKernelGGL(kern, grid, dim3(2 * THREADS), lds, st, pa, pb, cg, d, ep);
     return launch_status("mc_igemm");
 }
 
@@ -440,6 +501,7 @@ int launch_rows_cols(const typename AADDR::P& pa, const typename BADDR::P& pb, c
         MC_FORCE(1, 1) MC_FORCE(2, 1) MC_FORCE(3, 1) MC_FORCE(5, 1)
 #undef MC_FORCE
         if (fm == 2 && fn == 3) return launch_cfg<AADDR, BADDR, 2, 3, 2, 2, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+        if (fm == 3 && fn == 2) return launch_cfg<AADDR, BADDR, 3, 2, 2, 2, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
     }
     // Measured on MI355X (tools/igemm_sweep.py): 128-column tiles (one 32-column strip per wave) beat
     // 256-column tiles on every shape of the BASELINE nets; 192-column tiles (2x2 waves, 3 strips each)
@@ -472,7 +534,7 @@ int make_convg(ConvG& cg, int N, int C, int H, int W, int F, int fs, int pad, in
     MC_REQUIRE(C % groups == 0 && F % groups == 0, "%s: channels (%d) and filters (%d) must be divisible by groups (%d)",
                who, C, F, groups);
     const long biggest = (long)N * (long)((long)C * H * W > (long)F * MY * MX ? (long)C * H * W : (long)F * MY * MX);
-    MC_REQUIRE(biggest < (1L << 31), "%s: tensor with %ld elements exceeds 32-bit indexing", who, biggest);
+    MC_REQUIRE(biggest < (1L << 30), "%s: tensor with %ld elements exceeds the 4 GiB buffer-descriptor range", who, biggest);
     // fdiv() decodes the K index with a float reciprocal, exact below 2^22
     MC_REQUIRE((long)MY * MX * N < (1L << 22) && (long)(C / groups) * fs * fs < (1L << 22) && (long)fs * fs * (F / groups) < (1L << 22),
                "%s: modules*images, channels*taps and taps*filters must each be < 2^22", who);
@@ -494,10 +556,10 @@ int conv_filter_acts_impl(const float* images, const float* filters, float* targ
     ConvG cg;
     int rc = make_convg(cg, N, C, H, W, F, fs, pad, stride, MY, MX, groups, 0, "convFilterActs");
     if (rc) return rc;
-    Dims d{cg.fpg, cg.M * N, cg.fc * cg.fp, cg.fc * cg.fp, groups};
+    Dims d{cg.fpg, cg.M * N, cg.fc * cg.fp, cg.fc * cg.fp, groups, 0};
     Epi ep{targets, cg.M * N, cg.fpg, 0, 0, scaleOutput, scaleTargets, biases, neuron};
-    MatP pa{filters, F, cg.fpg, cg.fpg};  // filters[k*F + g*fpg + f]
-    ConvP pb{images, cg.M * N};
+    MatP pa{filters, F, cg.fpg, cg.fpg, (unsigned)((size_t)cg.fc * cg.fp * F * 4)};  // filters[k*F + g*fpg + f]
+    ConvP pb{images, cg.M * N, (unsigned)((size_t)C * H * W * N * 4)};
     const bool vec = (N % 4 == 0) && (cg.fpg % 4 == 0) && (F % 4 == 0) && aligned16(images) && aligned16(filters);
     if (vec) return launch_rows_cols<MatNatAddr, PatchNatAddr, MC_BK, 4>(pa, pb, cg, d, ep, 1, st);
     return launch_rows_cols<MatNatAddr, PatchNatAddr, MC_BK, 1>(pa, pb, cg, d, ep, 1, st);
@@ -512,10 +574,10 @@ int conv_img_acts_impl(const float* hidActs, const float* filters, float* target
     ConvG cg;
     int rc = make_convg(cg, N, C, H, W, F, fs, pad, stride, MY, MX, groups, 0, "convImgActs");
     if (rc) return rc;
-    Dims d{cg.fc, H * W * N, cg.fp * cg.fpg, cg.fp * cg.fpg, groups};
+    Dims d{cg.fc, H * W * N, cg.fp * cg.fpg, cg.fp * cg.fpg, groups, 0};
     Epi ep{targets, H * W * N, cg.fc, 0, 0, scaleOutput, scaleTargets, nullptr, MC_NEURON_NONE};
-    ConvP pa{filters + 0, cg.fc};
-    ConvP pb{hidActs, H * W * N};
+    ConvP pa{filters, cg.fc, (unsigned)((size_t)cg.fc * cg.fp * F * 4)};
+    ConvP pb{hidActs, H * W * N, (unsigned)((size_t)F * cg.M * N * 4)};
     // group offset of the A operand rows: channel c of group g uses filter rows (cl*fp+p), columns g*fpg+fl
     const bool vec = (N % 4 == 0) && (cg.fpg % 4 == 0) && (F % 4 == 0) && aligned16(hidActs) && aligned16(filters);
     if (vec) return launch_rows_cols<FiltTAddr, HidNatAddr, MC_BK, 4>(pa, pb, cg, d, ep, 1, st);
@@ -534,10 +596,10 @@ int conv_weight_acts_impl(const float* images, const float* hidActs, float* targ
     if (partialSum <= 0) partialSum = cg.M;
     MC_REQUIRE(cg.M % partialSum == 0, "convWeightActs: partialSum (%d) must divide numModules (%d)", partialSum, cg.M);
     const int chunks = cg.M / partialSum;
-    Dims d{cg.fc * cg.fp, cg.fpg, cg.M * N, partialSum * N, groups};
+    Dims d{cg.fc * cg.fp, cg.fpg, cg.M * N, partialSum * N, groups, 0};
     Epi ep{targets, F, 0, cg.fpg, (long)cg.fc * cg.fp * F, scaleOutput, scaleTargets, nullptr, MC_NEURON_NONE};
-    ConvP pa{images, cg.fc * cg.fp};
-    MatP pb{hidActs, cg.M * N, cg.fpg, cg.fpg * cg.M * N};  // hid[(g*fpg+f)*M*N + k]
+    ConvP pa{images, cg.fc * cg.fp, (unsigned)((size_t)C * H * W * N * 4)};
+    MatP pb{hidActs, cg.M * N, cg.fpg, cg.fpg * cg.M * N, (unsigned)((size_t)F * cg.M * N * 4)};  // hid[(g*fpg+f)*M*N + k]
     const bool vec = (N % 4 == 0) && aligned16(images) && aligned16(hidActs);
     if (vec) return launch_rows_cols<PatchKcAddr, MatKcAddr, 32, 4>(pa, pb, cg, d, ep, chunks, st);
     return launch_rows_cols<PatchKcAddr, MatKcAddr, 32, 1>(pa, pb, cg, d, ep, chunks, st);
@@ -556,10 +618,13 @@ int gemm_impl(const float* A, const float* B, float* Cm, int m, int n, int k, in
         kChunk = (kChunk + 31) / 32 * 32;
         chunks = ceil_div(k, kChunk);
     }
-    Dims d{m, n, k, kChunk, 1};
+    Dims d{m, n, k, kChunk, 1, 0};
     Epi ep{Cm, ldc, 0, 0, chunkStride, alpha, beta, rowBias, neuron};
-    MatP pa{A, lda, m, 0};
-    MatP pb{B, ldb, n, 0};
+    // operand extents in bytes: (rows - 1) * ld + row length
+    const size_t ea = transA ? (size_t)(k - 1) * lda + m : (size_t)(m - 1) * lda + k;
+    const size_t eb = transB ? (size_t)(n - 1) * ldb + k : (size_t)(k - 1) * ldb + n;
+    MatP pa{A, lda, m, 0, (unsigned)(ea * 4)};
+    MatP pb{B, ldb, n, 0, (unsigned)(eb * 4)};
     const bool al = aligned16(A) && aligned16(B) && lda % 4 == 0 && ldb % 4 == 0;
     // vector loads need the contiguous extent of each operand to be a multiple of 4
     const bool va = transA ? (m % 4 == 0) : (k % 4 == 0);
