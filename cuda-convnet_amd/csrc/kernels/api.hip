@@ -1,5 +1,6 @@
 // api.hip -- extern "C" entry points for the contraction kernels (conv / local / dense),
 // error reporting, device query, split-K reduction, and the unshared (local) layer kernels.
+#include <stdlib.h>
 #include <string.h>
 #include "mc_common.h"
 
@@ -202,6 +203,8 @@ inline int grid_items(size_t items) {
 }
 
 int pick_gemm_chunks(int m, int n, int k) {
+    static const char* forced = getenv("MC_GEMM_CHUNKS");   // tuning knob (benchmarks only)
+    if (forced && forced[0]) return atoi(forced) < 1 ? 1 : atoi(forced);
     // tiles of the shape launch_rows_cols will pick for a long-k product: 128 x 192 when that pads the
     // column extent less, else 96 x 128
     const bool wide = (long)ceil_div(n, 192) * 192 < (long)ceil_div(n, 128) * 128 && m > 96;

@@ -30,6 +30,16 @@
 #include <stdlib.h>
 #include "mc_common.h"
 
+#ifdef MC_STAMP   // diagnostic build only (tools/build_variant.sh stamp -DMC_STAMP): where do the K steps spend their cycles?
+__device__ unsigned long long g_stamp[8192 * 8];
+extern "C" int mc_debug_read_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
+}
+#define STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(var) do { } while (0)
+#endif
+
 namespace mc {
 namespace {
 
@@ -293,14 +303,15 @@ template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int 
 __global__ void __launch_bounds__(2 * THREADS)
 mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     static_assert(WM * WN == 4, "4 consumer waves");
+    static_assert(NS >= 2, "at least two tile register sets");
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     typedef Loader<AADDR, BM, BK, VEC> LA;
     typedef Loader<BADDR, BN, BK, VEC> LB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sA0 = smem;
-    float* sA1 = smem + LA::LDS_FLOATS;
-    float* sB0 = smem + 2 * LA::LDS_FLOATS;
-    float* sB1 = sB0 + LB::LDS_FLOATS;
+    // three LDS stages, stage s = [A tile | B tile]: during K step t the consumers read stage t % 3 (and,
+    // near its end, prefetch the first fragments of stage (t+1) % 3, complete since the previous barrier)
+    // while the producers fill stage (t+2) % 3.
+    constexpr int STAGE = LA::LDS_FLOATS + LB::LDS_FLOATS;
 
     // column-tile index: with d.xcdSwizzle the grid's x extent is a multiple of 8 and workgroups are dealt
     // round-robin over the 8 XCDs, so workgroup b -> tile (b % 8) * (gridDim.x / 8) + b / 8 keeps
@@ -314,50 +325,80 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
 
     if (threadIdx.x >= THREADS) {
         // ------------------------------ producer waves ------------------------------
-        // Register ring of NS tile sets: tile u lives in set u % NS.  During K step t the consumers read
-        // LDS buffer t & 1; the producers first issue tile t+NS's loads into the set that tile t left
-        // free, then write tile t+1 (the oldest loads in flight) to LDS buffer (t+1) & 1.  Up to NS tiles
-        // are in flight per workgroup: under load an L2 / Infinity-Cache read takes 1-2 us, several K steps.
+        // Register ring of NS tile sets: tile u lives in set u % NS and goes to LDS stage u % 3.  Tiles 0
+        // and 1 are staged before the first barrier; during K step t tile t+2 (the oldest loads in
+        // flight) is written to its stage and its register set is refilled with tile t+2+NS, so NS-1..NS
+        // tiles are in flight per workgroup (under load an L2 / Infinity-Cache read takes 1-2 us).
         const int tid = threadIdx.x - THREADS;
+#ifndef MC_NO_PRODUCER_PRIO
+        // The consumers were dispatched first, so at equal priority they win every vector-issue arbitration
+        // and a SIMD with two MFMA waves leaves the producers ~1 issue slot per 30 cycles (measured with
+        // MC_STAMP).  Producers are short bursts between long waits: give them the slot when they want it.
+        __builtin_amdgcn_s_setprio(3);
+#endif
         const __amdgpu_buffer_rsrc_t ra = make_rsrc(AADDR::base(pa), pa.bytes), rb = make_rsrc(BADDR::base(pb), pb.bytes);
         LA as[NS];
         LB bs[NS];
+        auto fetch = [&](auto& la, auto& lb, int u) {
+            la.fetch(ra, pa, cg, g, kbeg + u * BK, kend, i0, tid);
+            lb.fetch(rb, pb, cg, g, kbeg + u * BK, kend, j0, tid);
+        };
+        auto commit = [&](const auto& la, const auto& lb, int stage) {
+            la.commit(smem + stage * STAGE, tid);
+            lb.commit(smem + stage * STAGE + LA::LDS_FLOATS, tid);
+        };
 #pragma unroll
         for (int u = 0; u < NS; ++u)
-            if (u < nk) {
-                as[u].fetch(ra, pa, cg, g, kbeg + u * BK, kend, i0, tid);
-                bs[u].fetch(rb, pb, cg, g, kbeg + u * BK, kend, j0, tid);
-            }
-        as[0].commit(sA0, tid);
-        bs[0].commit(sB0, tid);
-        lds_done_barrier();   // tile 0 visible
-        int t = 0;
+            if (u < nk) fetch(as[u], bs[u], u);
+        commit(as[0], bs[0], 0);
+        if (NS < nk) fetch(as[0], bs[0], NS);
+        if (1 < nk) {
+            commit(as[1 % NS], bs[1 % NS], 1);
+            if (NS + 1 < nk) fetch(as[1 % NS], bs[1 % NS], NS + 1);
+        }
+        lds_done_barrier();   // tiles 0 and 1 visible
+        int t = 0, stage = 2; // stage of tile t+2
+        unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, accC = 0, accF = 0, accL = 0, accB = 0;
+        (void)p0; (void)p1; (void)p2; (void)p3; (void)p4; (void)accC; (void)accF; (void)accL; (void)accB;
         // steady state: NS K steps per trip, no conditionals inside (keeps the compiler's vmcnt counts exact)
-        for (; t + 2 * NS <= nk; t += NS) {
+        for (; t + 2 * NS + 2 <= nk; t += NS) {
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
-                const int tt = t + j;
-                as[j].fetch(ra, pa, cg, g, kbeg + (tt + NS) * BK, kend, i0, tid);
-                bs[j].fetch(rb, pb, cg, g, kbeg + (tt + NS) * BK, kend, j0, tid);
-                as[(j + 1) % NS].commit(((tt + 1) & 1) ? sA1 : sA0, tid);
-                bs[(j + 1) % NS].commit(((tt + 1) & 1) ? sB1 : sB0, tid);
-                lds_done_barrier();   // end of K step tt
+                const int u = t + j + 2;                 // tile written during K step t+j; set (j+2) % NS
+                STAMP(p0);
+                commit(as[(j + 2) % NS], bs[(j + 2) % NS], stage);
+                STAMP(p1);
+                fetch(as[(j + 2) % NS], bs[(j + 2) % NS], u + NS);
+                STAMP(p2);
+                stage = stage == 2 ? 0 : stage + 1;
+#ifdef MC_STAMP
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                STAMP(p3);
+#endif
+                lds_done_barrier();   // end of K step t+j
+                STAMP(p4);
+#ifdef MC_STAMP
+                accC += p1 - p0; accF += p2 - p1; accL += p3 - p2; accB += p4 - p3;
+#endif
             }
         }
-        // tail: fewer than 2*NS K steps left; t is a multiple of NS, so the set indices stay static
+#ifdef MC_STAMP
+        if (tid == 0) {
+            const int blk = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            if (blk < 8192) { g_stamp[blk * 8 + 4] = accC; g_stamp[blk * 8 + 5] = accF; g_stamp[blk * 8 + 6] = accL; g_stamp[blk * 8 + 7] = accB; }
+        }
+#endif
+        // tail: t is a multiple of NS, so the set indices stay static
         for (; t < nk; t += NS) {
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
-                const int tt = t + j;
+                const int tt = t + j, u = tt + 2;
                 if (tt < nk) {
-                    if (tt + NS < nk) {
-                        as[j].fetch(ra, pa, cg, g, kbeg + (tt + NS) * BK, kend, i0, tid);
-                        bs[j].fetch(rb, pb, cg, g, kbeg + (tt + NS) * BK, kend, j0, tid);
+                    if (u < nk) {
+                        commit(as[(j + 2) % NS], bs[(j + 2) % NS], stage);
+                        if (u + NS < nk) fetch(as[(j + 2) % NS], bs[(j + 2) % NS], u + NS);
                     }
-                    if (tt + 1 < nk) {
-                        as[(j + 1) % NS].commit(((tt + 1) & 1) ? sA1 : sA0, tid);
-                        bs[(j + 1) % NS].commit(((tt + 1) & 1) ? sB1 : sB0, tid);
-                    }
+                    stage = stage == 2 ? 0 : stage + 1;
                     lds_done_barrier();   // end of K step tt
                 }
             }
@@ -379,51 +420,64 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    lds_done_barrier();   // tile 0 visible
+    // LDS -> register fragments, software-pipelined ACROSS K steps: "slab" s holds the operands of one
+    // MFMA k-step (2 k values: lane half h supplies k = kof(s) + h-dependent offset).  The reads of slab
+    // s+PF are issued before the MFMAs of slab s; the last PF slabs of a K step prefetch the first PF
+    // slabs of the NEXT stage, so the matrix pipe does not drain at the barrier.
+    constexpr int SLABS = BK / 2, PF = 2;
+    static_assert(SLABS >= 4 + PF, "prefetch into consumed fragment registers");
+    float af[SLABS][MT], bf[SLABS][NT];
+    auto load_slab = [&](const float* cA, const float* cB, int s_) {
+        // slab s_ = (k8, e): k = k8*8 + 4*h + e.  NAT operands read one float per slab; KC
+        // operands fetch the four slabs of a k8 group with one ds_read_b128 when e == 0.
+        const int k8 = s_ >> 2, e = s_ & 3;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const int row = (wm * MT + a) * 32 + l31;
+            if (LA::KC) {
+                if (e == 0) {
+                    const float4 v = reinterpret_cast<const float4*>(cA)[(k8 * 2 + h) * LA::ROWSP + row];
+                    af[s_][a] = v.x; af[s_ + 1][a] = v.y; af[s_ + 2][a] = v.z; af[s_ + 3][a] = v.w;
+                }
+            } else {
+                af[s_][a] = cA[(k8 * 8 + 4 * h + e) * BM + row];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int col = (wn * NT + b) * 32 + l31;
+            if (LB::KC) {
+                if (e == 0) {
+                    const float4 v = reinterpret_cast<const float4*>(cB)[(k8 * 2 + h) * LB::ROWSP + col];
+                    bf[s_][b] = v.x; bf[s_ + 1][b] = v.y; bf[s_ + 2][b] = v.z; bf[s_ + 3][b] = v.w;
+                }
+            } else {
+                bf[s_][b] = cB[(k8 * 8 + 4 * h + e) * BN + col];
+            }
+        }
+    };
 
+    lds_done_barrier();   // tiles 0 and 1 visible
+#pragma unroll
+    for (int s_ = 0; s_ < PF; ++s_) load_slab(smem, smem + LA::LDS_FLOATS, s_);
+    int stage = 0;
+    unsigned long long c0 = 0, c1 = 0, c2 = 0, cStart = 0, accM = 0, accW = 0;
+    (void)c0; (void)c1; (void)c2; (void)cStart; (void)accM; (void)accW;
+    STAMP(cStart);
+#ifdef MC_STAMP
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int t = 0; t < nk; ++t) {
-        const float* cA = (t & 1) ? sA1 : sA0;
-        const float* cB = (t & 1) ? sB1 : sB0;
-        // LDS -> register fragments, software-pipelined: "slab" s holds the operands of one MFMA
-        // k-step (2 k values: lane half h supplies k = kof(s) + h-dependent offset).  The reads of
-        // slab s+PF are issued before the MFMAs of slab s, so the LDS latency hides behind
-        // PF * MT*NT * 64 cycles of matrix work instead of stalling every other MFMA.
-        constexpr int SLABS = BK / 2, PF = 2;
-        float af[SLABS][MT], bf[SLABS][NT];
-        auto load_slab = [&](int s_) {
-            // slab s_ = (k8, e): k = k8*8 + 4*h + e.  NAT operands read one float per slab; KC
-            // operands fetch the four slabs of a k8 group with one ds_read_b128 when e == 0.
-            const int k8 = s_ >> 2, e = s_ & 3;
-#pragma unroll
-            for (int a = 0; a < MT; ++a) {
-                const int row = (wm * MT + a) * 32 + l31;
-                if (LA::KC) {
-                    if (e == 0) {
-                        const float4 v = reinterpret_cast<const float4*>(cA)[(k8 * 2 + h) * LA::ROWSP + row];
-                        af[s_][a] = v.x; af[s_ + 1][a] = v.y; af[s_ + 2][a] = v.z; af[s_ + 3][a] = v.w;
-                    }
-                } else {
-                    af[s_][a] = cA[(k8 * 8 + 4 * h + e) * BM + row];
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < NT; ++b) {
-                const int col = (wn * NT + b) * 32 + l31;
-                if (LB::KC) {
-                    if (e == 0) {
-                        const float4 v = reinterpret_cast<const float4*>(cB)[(k8 * 2 + h) * LB::ROWSP + col];
-                        bf[s_][b] = v.x; bf[s_ + 1][b] = v.y; bf[s_ + 2][b] = v.z; bf[s_ + 3][b] = v.w;
-                    }
-                } else {
-                    bf[s_][b] = cB[(k8 * 8 + 4 * h + e) * BN + col];
-                }
-            }
-        };
-#pragma unroll
-        for (int s_ = 0; s_ < PF; ++s_) load_slab(s_);
+        const int nstage = stage == 2 ? 0 : stage + 1;
+        STAMP(c0);
+        const float* cA = smem + stage * STAGE;
+        const float* cB = cA + LA::LDS_FLOATS;
+        const float* nA = smem + nstage * STAGE;   // on the last K step this stage holds stale data: read, never used
+        const float* nB = nA + LA::LDS_FLOATS;
 #pragma unroll
         for (int s_ = 0; s_ < SLABS; ++s_) {
-            if (s_ + PF < SLABS) load_slab(s_ + PF);
+            if (s_ + PF < SLABS) load_slab(cA, cB, s_ + PF);
+            else load_slab(nA, nB, s_ + PF - SLABS);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < MT; ++a)
@@ -432,8 +486,25 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s_][a], bf[s_][b], acc[a][b], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        lds_done_barrier();   // end of K step t: every fragment read of this buffer has been consumed
+        // end of K step t.  No LDS wait here: every read of this stage has been consumed by an MFMA above,
+        // and the prefetched stage is not rewritten before the barrier after next.
+        STAMP(c1);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        STAMP(c2);
+#ifdef MC_STAMP
+        accM += c1 - c0; accW += c2 - c1;
+#endif
+        stage = nstage;
     }
+#ifdef MC_STAMP
+    if (tid == 0) {
+        const int blk = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+        if (blk < 8192) { g_stamp[blk * 8 + 0] = c2 - cStart; g_stamp[blk * 8 + 1] = accM; g_stamp[blk * 8 + 2] = ((rt1 - rt0) << 32) | (accW & 0xFFFFFFFFull); g_stamp[blk * 8 + 3] = (unsigned long long)nk; }
+    }
+#endif
 
     // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* C = ep.C + q * ep.chunkStride;
@@ -468,7 +539,7 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     typedef Loader<AADDR, BM, BK, VEC> LA;
     typedef Loader<BADDR, BN, BK, VEC> LB;
-    constexpr size_t lds = 2 * (LA::LDS_FLOATS + LB::LDS_FLOATS) * sizeof(float);
+    constexpr size_t lds = 3 * (LA::LDS_FLOATS + LB::LDS_FLOATS) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = mc_igemm<AADDR, BADDR, MT, NT, WM, WN, BK, VEC, NS>;
     Dims d = d0;
@@ -503,20 +574,20 @@ int launch_rows_cols(const typename AADDR::P& pa, const typename BADDR::P& pb, c
         if (fm == 2 && fn == 3) return launch_cfg<AADDR, BADDR, 2, 3, 2, 2, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
         if (fm == 3 && fn == 2) return launch_cfg<AADDR, BADDR, 3, 2, 2, 2, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
     }
-    // Measured on MI355X (tools/igemm_sweep.py): 128-column tiles (one 32-column strip per wave) beat
-    // 256-column tiles on every shape of the BASELINE nets; 192-column tiles (2x2 waves, 3 strips each)
-    // are used when they cut the padding of the column extent (F = 192 weight gradients: 256 -> 192).
+    // Measured on MI355X (tools/tile_sweep.py over the NIN shapes): 128-column tiles (one 32-column strip per
+    // consumer wave) win almost everywhere; exactly 160 rows (NIN cccp1 / cccp2) take one 160-row tile so the
+    // big operand is read once; 192-column tiles (2x2 waves, 3 strips each) are used when they cut the
+    // padding of the column extent (F = 192 weight gradients: 256 -> 192).
     const long z = (long)chunks * d.groups;
     const int mt32 = ceil_div(d.Mg, 32);
+    const long colTiles = ceil_div(d.Ng, 128);
+    if (mt32 == 5 && colTiles * z >= num_cus())
+        return launch_cfg<AADDR, BADDR, 5, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
     const long pad128 = (long)ceil_div(d.Ng, 128) * 128, pad192 = (long)ceil_div(d.Ng, 192) * 192;
     if (pad192 < pad128 && mt32 >= 4 && (long)ceil_div(d.Mg, 128) * ceil_div(d.Ng, 192) * z >= num_cus())
         return launch_cfg<AADDR, BADDR, 2, 3, 2, 2, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
     // rows: the largest of {96, 64, 32} that divides the 32-padded row count, shrunk while the grid
     // would leave CUs idle
-    const long colTiles = ceil_div(d.Ng, 128);
-    // exactly 160 rows (NIN cccp1 / cccp2): one 160-row tile reads the big operand once
-    if (mt32 == 5 && colTiles * z >= 2L * num_cus())
-        return launch_cfg<AADDR, BADDR, 5, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
     int MTsel = (mt32 % 3 == 0) ? 3 : (mt32 % 2 == 0 || mt32 >= 8) ? 2 : 1;
     while (MTsel > 1 && (long)ceil_div(d.Mg, 32 * MTsel) * colTiles * z < num_cus()) --MTsel;
     if (MTsel == 3) return launch_cfg<AADDR, BADDR, 3, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
