@@ -36,7 +36,7 @@ int conv_img_acts_impl(const float*, const float*, float*, int, int, int, int, i
 int conv_weight_acts_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int, int, int,
                           float, float, hipStream_t);
 int gemm_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, float, float, const float*, int,
-              int, long, hipStream_t);
+              const float*, int, int, long, hipStream_t);
 
 namespace {
 
@@ -44,7 +44,7 @@ constexpr int TPB = 256;
 
 // out[i][j] = beta*C + alpha*sum_q slab[q][i][j] (+bias[i]) (relu)
 __global__ void k_splitk_reduce(const float* __restrict__ slabs, float* C, int m, int n, int ldc, int chunks, float alpha,
-                                float beta, const float* __restrict__ bias, int act) {
+                                float beta, const float* __restrict__ bias, int act, const float* __restrict__ mask, int ldmask) {
     const size_t total = (size_t)m * n;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int i = (int)(e / n), j = (int)(e - (size_t)i * n);
@@ -55,6 +55,7 @@ __global__ void k_splitk_reduce(const float* __restrict__ slabs, float* C, int m
         if (beta != 0.f) v += beta * C[idx];
         if (bias) v += bias[i];
         if (act == MC_NEURON_RELU) v = v < 0.f ? 0.f : v;
+        if (mask && !(mask[(size_t)i * ldmask + j] > 0.f)) v = 0.f;
         C[idx] = v;
     }
 }
@@ -63,7 +64,8 @@ __global__ void k_splitk_reduce(const float* __restrict__ slabs, float* C, int m
 // slabs qg, qg+16, ... in order, then the 16 partials are added in a fixed LDS tree (deterministic).
 // Requires n % 4 == 0, ldc % 4 == 0 and 16-byte aligned pointers.
 __global__ void __launch_bounds__(256) k_splitk_reduce_tall(const float4* __restrict__ slabs, float* C, int m, int n4, int ldc, int chunks,
-                                                              float alpha, float beta, const float* __restrict__ bias, int act) {
+                                                              float alpha, float beta, const float* __restrict__ bias, int act,
+                                                              const float* __restrict__ mask, int ldmask) {
     __shared__ float4 sh[16][17];
     const int cg = threadIdx.x & 15, qg = threadIdx.x >> 4;
     const size_t total4 = (size_t)m * n4;
@@ -94,6 +96,13 @@ __global__ void __launch_bounds__(256) k_splitk_reduce_tall(const float4* __rest
         }
         if (bias) { const float b = bias[i]; v.x += b; v.y += b; v.z += b; v.w += b; }
         if (act == MC_NEURON_RELU) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }
+        if (mask) {
+            const float* mk = mask + (size_t)i * ldmask + 4 * j4;
+            if (!(mk[0] > 0.f)) v.x = 0.f;
+            if (!(mk[1] > 0.f)) v.y = 0.f;
+            if (!(mk[2] > 0.f)) v.z = 0.f;
+            if (!(mk[3] > 0.f)) v.w = 0.f;
+        }
         *dst = v;
     }
 }
@@ -346,20 +355,21 @@ size_t mc_gemm_workspace_bytes(int m, int n, int k) {
     return chunks > 1 ? (size_t)chunks * m * n * sizeof(float) : 0;
 }
 
-int mc_gemm(const float* A, const float* B, float* C, int m, int n, int k, int transA, int transB, int lda, int ldb,
-            int ldc, float scaleTargets, float scaleOutput, const float* rowBias, int neuron, void* workspace,
-            size_t workspaceBytes, mcStream_t s) {
-    MC_REQUIRE(A && B && C, "mc_gemm: null pointer");
-    MC_REQUIRE(m > 0 && n > 0 && k > 0, "mc_gemm: non-positive dimension (%d,%d,%d)", m, n, k);
-    MC_REQUIRE(lda >= (transA ? m : k) && ldb >= (transB ? k : n) && ldc >= n, "mc_gemm: leading dimension too small");
-    MC_REQUIRE(neuron == MC_NEURON_NONE || neuron == MC_NEURON_RELU, "mc_gemm: unknown neuron %d", neuron);
+static int gemm_entry(const char* who, const float* A, const float* B, float* C, int m, int n, int k, int transA, int transB, int lda,
+                      int ldb, int ldc, float scaleTargets, float scaleOutput, const float* rowBias, int neuron, const float* mask,
+                      int ldmask, void* workspace, size_t workspaceBytes, mcStream_t s) {
+    MC_REQUIRE(A && B && C, "%s: null pointer", who);
+    MC_REQUIRE(m > 0 && n > 0 && k > 0, "%s: non-positive dimension (%d,%d,%d)", who, m, n, k);
+    MC_REQUIRE(lda >= (transA ? m : k) && ldb >= (transB ? k : n) && ldc >= n, "%s: leading dimension too small", who);
+    MC_REQUIRE(neuron == MC_NEURON_NONE || neuron == MC_NEURON_RELU, "%s: unknown neuron %d", who, neuron);
+    MC_REQUIRE(!mask || ldmask >= n, "%s: mask leading dimension too small", who);
     MC_REQUIRE((size_t)(transA ? k : m) * lda < (1ull << 30) && (size_t)(transB ? n : k) * ldb < (1ull << 30) &&
                    (size_t)m * ldc < (1ull << 31),
-               "mc_gemm: operand exceeds the 4 GiB buffer-descriptor range");
+               "%s: operand exceeds the 4 GiB buffer-descriptor range", who);
     int chunks = pick_gemm_chunks(m, n, k);
     if (chunks > 1 && workspace && workspaceBytes >= (size_t)chunks * m * n * sizeof(float) && aligned16(workspace)) {
         float* slabs = static_cast<float*>(workspace);
-        int rc = gemm_impl(A, B, slabs, m, n, k, transA, transB, lda, ldb, n, 0.f, 1.f, nullptr, MC_NEURON_NONE, chunks,
+        int rc = gemm_impl(A, B, slabs, m, n, k, transA, transB, lda, ldb, n, 0.f, 1.f, nullptr, MC_NEURON_NONE, nullptr, 0, chunks,
                            (long)m * n, S(s));
         if (rc) return rc;
         // gemm_impl may round the chunk size up; recompute how many slabs were written
@@ -367,14 +377,30 @@ int mc_gemm(const float* A, const float* B, float* C, int m, int n, int k, int t
         const int written = ceil_div(k, kChunk);
         if (n % 4 == 0 && ldc % 4 == 0 && aligned16(C) && written >= 16)
             hipLaunchKernelGGL(k_splitk_reduce_tall, dim3(ceil_div((long)m * (n / 4), 16)), dim3(256), 0, S(s),
-                               reinterpret_cast<const float4*>(slabs), C, m, n / 4, ldc, written, scaleOutput, scaleTargets, rowBias, neuron);
+                               reinterpret_cast<const float4*>(slabs), C, m, n / 4, ldc, written, scaleOutput, scaleTargets, rowBias, neuron,
+                               mask, ldmask);
         else
             hipLaunchKernelGGL(k_splitk_reduce, dim3(grid_items((size_t)m * n)), dim3(TPB), 0, S(s), slabs, C, m, n, ldc,
-                               written, scaleOutput, scaleTargets, rowBias, neuron);
+                               written, scaleOutput, scaleTargets, rowBias, neuron, mask, ldmask);
         return launch_status("mc_gemm(split-k reduce)");
     }
-    return gemm_impl(A, B, C, m, n, k, transA, transB, lda, ldb, ldc, scaleTargets, scaleOutput, rowBias, neuron, 1, 0,
+    return gemm_impl(A, B, C, m, n, k, transA, transB, lda, ldb, ldc, scaleTargets, scaleOutput, rowBias, neuron, mask, ldmask, 1, 0,
                      S(s));
+}
+
+int mc_gemm(const float* A, const float* B, float* C, int m, int n, int k, int transA, int transB, int lda, int ldb,
+            int ldc, float scaleTargets, float scaleOutput, const float* rowBias, int neuron, void* workspace,
+            size_t workspaceBytes, mcStream_t s) {
+    return gemm_entry("mc_gemm", A, B, C, m, n, k, transA, transB, lda, ldb, ldc, scaleTargets, scaleOutput, rowBias, neuron, nullptr, 0,
+                      workspace, workspaceBytes, s);
+}
+
+int mc_gemm_relu_grad(const float* A, const float* B, float* C, int m, int n, int k, int transA, int transB, int lda, int ldb,
+                      int ldc, float scaleTargets, float scaleOutput, const float* reluActs, int ldr, void* workspace,
+                      size_t workspaceBytes, mcStream_t s) {
+    MC_REQUIRE(reluActs, "mc_gemm_relu_grad: null reluActs");
+    return gemm_entry("mc_gemm_relu_grad", A, B, C, m, n, k, transA, transB, lda, ldb, ldc, scaleTargets, scaleOutput, nullptr,
+                      MC_NEURON_NONE, reluActs, ldr, workspace, workspaceBytes, s);
 }
 
 }  // extern "C"

@@ -79,6 +79,8 @@ struct Epi {
     float alpha, beta;
     const float* bias;  // per output row (after group offset), nullable
     int act;            // MC_NEURON_*
+    const float* mask;  // nullable: outputs whose mask element is not > 0 are written as 0 (relu gradient)
+    int ldmask;
 };
 
 // exact floor(a / d) for 0 <= a < 2^22 using a precomputed float reciprocal
@@ -523,6 +525,7 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
                     if (ep.beta != 0.f) v += ep.beta * C[idx];
                     if (ep.bias) v += ep.bias[row];
                     if (ep.act == MC_NEURON_RELU) v = v < 0.f ? 0.f : v;
+                    if (ep.mask && !(ep.mask[(long)row * ep.ldmask + j + g * ep.colG] > 0.f)) v = 0.f;
                     C[idx] = v;
                 }
             }
@@ -628,7 +631,7 @@ int conv_filter_acts_impl(const float* images, const float* filters, float* targ
     int rc = make_convg(cg, N, C, H, W, F, fs, pad, stride, MY, MX, groups, 0, "convFilterActs");
     if (rc) return rc;
     Dims d{cg.fpg, cg.M * N, cg.fc * cg.fp, cg.fc * cg.fp, groups, 0};
-    Epi ep{targets, cg.M * N, cg.fpg, 0, 0, scaleOutput, scaleTargets, biases, neuron};
+    Epi ep{targets, cg.M * N, cg.fpg, 0, 0, scaleOutput, scaleTargets, biases, neuron, nullptr, 0};
     MatP pa{filters, F, cg.fpg, cg.fpg, (unsigned)((size_t)cg.fc * cg.fp * F * 4)};  // filters[k*F + g*fpg + f]
     ConvP pb{images, cg.M * N, (unsigned)((size_t)C * H * W * N * 4)};
     const bool vec = (N % 4 == 0) && (cg.fpg % 4 == 0) && (F % 4 == 0) && aligned16(images) && aligned16(filters);
@@ -646,7 +649,7 @@ int conv_img_acts_impl(const float* hidActs, const float* filters, float* target
     int rc = make_convg(cg, N, C, H, W, F, fs, pad, stride, MY, MX, groups, 0, "convImgActs");
     if (rc) return rc;
     Dims d{cg.fc, H * W * N, cg.fp * cg.fpg, cg.fp * cg.fpg, groups, 0};
-    Epi ep{targets, H * W * N, cg.fc, 0, 0, scaleOutput, scaleTargets, nullptr, MC_NEURON_NONE};
+    Epi ep{targets, H * W * N, cg.fc, 0, 0, scaleOutput, scaleTargets, nullptr, MC_NEURON_NONE, nullptr, 0};
     ConvP pa{filters, cg.fc, (unsigned)((size_t)cg.fc * cg.fp * F * 4)};
     ConvP pb{hidActs, H * W * N, (unsigned)((size_t)F * cg.M * N * 4)};
     // group offset of the A operand rows: channel c of group g uses filter rows (cl*fp+p), columns g*fpg+fl
@@ -668,7 +671,7 @@ int conv_weight_acts_impl(const float* images, const float* hidActs, float* targ
     MC_REQUIRE(cg.M % partialSum == 0, "convWeightActs: partialSum (%d) must divide numModules (%d)", partialSum, cg.M);
     const int chunks = cg.M / partialSum;
     Dims d{cg.fc * cg.fp, cg.fpg, cg.M * N, partialSum * N, groups, 0};
-    Epi ep{targets, F, 0, cg.fpg, (long)cg.fc * cg.fp * F, scaleOutput, scaleTargets, nullptr, MC_NEURON_NONE};
+    Epi ep{targets, F, 0, cg.fpg, (long)cg.fc * cg.fp * F, scaleOutput, scaleTargets, nullptr, MC_NEURON_NONE, nullptr, 0};
     ConvP pa{images, cg.fc * cg.fp, (unsigned)((size_t)C * H * W * N * 4)};
     MatP pb{hidActs, cg.M * N, cg.fpg, cg.fpg * cg.M * N, (unsigned)((size_t)F * cg.M * N * 4)};  // hid[(g*fpg+f)*M*N + k]
     const bool vec = (N % 4 == 0) && aligned16(images) && aligned16(hidActs);
@@ -680,8 +683,8 @@ int conv_weight_acts_impl(const float* images, const float* hidActs, float* targ
 // dense: C(m,n) = beta*C + alpha*op(A)*op(B)
 // =================================================================================
 int gemm_impl(const float* A, const float* B, float* Cm, int m, int n, int k, int transA, int transB, int lda, int ldb,
-              int ldc, float beta, float alpha, const float* rowBias, int neuron, int chunks, long chunkStride,
-              hipStream_t st) {
+              int ldc, float beta, float alpha, const float* rowBias, int neuron, const float* mask, int ldmask, int chunks,
+              long chunkStride, hipStream_t st) {
     ConvG cg{};
     int kChunk = k;
     if (chunks > 1) {
@@ -690,7 +693,7 @@ int gemm_impl(const float* A, const float* B, float* Cm, int m, int n, int k, in
         chunks = ceil_div(k, kChunk);
     }
     Dims d{m, n, k, kChunk, 1, 0};
-    Epi ep{Cm, ldc, 0, 0, chunkStride, alpha, beta, rowBias, neuron};
+    Epi ep{Cm, ldc, 0, 0, chunkStride, alpha, beta, rowBias, neuron, mask, ldmask};
     // operand extents in bytes: (rows - 1) * ld + row length
     const size_t ea = transA ? (size_t)(k - 1) * lda + m : (size_t)(m - 1) * lda + k;
     const size_t eb = transB ? (size_t)(n - 1) * ldb + k : (size_t)(k - 1) * ldb + n;

@@ -43,6 +43,11 @@ __device__ __forceinline__ float4 veqmul(float4 i, float4 a, float4 g) {
     return make_float4((i.x == a.x) * g.x, (i.y == a.y) * g.y, (i.z == a.z) * g.z, (i.w == a.w) * g.w);
 }
 __device__ __forceinline__ float veqmul(float i, float a, float g) { return (i == a) * g; }
+// relu gradient mask: v where y > 0, else 0 (neuron.cuh:173-178)
+__device__ __forceinline__ float4 vposmask(float4 y, float4 v) {
+    return make_float4(y.x > 0.f ? v.x : 0.f, y.y > 0.f ? v.y : 0.f, y.z > 0.f ? v.z : 0.f, y.w > 0.f ? v.w : 0.f);
+}
+__device__ __forceinline__ float vposmask(float y, float v) { return y > 0.f ? v : 0.f; }
 __device__ __forceinline__ float4 vfma_s(float s, float4 a, float4 c) { return make_float4(s * a.x + c.x, s * a.y + c.y, s * a.z + c.z, s * a.w + c.w); }
 __device__ __forceinline__ float vfma_s(float s, float a, float c) { return s * a + c; }
 __device__ __forceinline__ float4 vpow(float4 a, float e) { return make_float4(powf(a.x, e), powf(a.y, e), powf(a.z, e), powf(a.w, e)); }
@@ -93,7 +98,7 @@ __device__ __forceinline__ void out_range(int p, int start, int subs, int stride
 }
 
 // ------------------------------------------------------------------ max-pool undo
-template <int V>
+template <int V, bool RELU>
 __global__ void k_max_undo(const float* __restrict__ imgs, const float* __restrict__ maxGrads,
                            const float* __restrict__ maxActs, float* target, int N, int C, int imgSize, int subsX,
                            int startX, int strideX, int outputsX, float sT, float sO) {
@@ -118,6 +123,7 @@ __global__ void k_max_undo(const float* __restrict__ imgs, const float* __restri
                     const size_t o = ((size_t)c * numOut + my * outputsX + mx) * N + n;
                     prod = vadd(prod, veqmul(img, VV::ld(maxActs + o), VV::ld(maxGrads + o)));
                 }
+            if (RELU) prod = vposmask(img, prod);   // the pooled images are a relu's output: its gradient mask, fused
         }
         float* t = target + (size_t)row * N + n;
         VV::st(t, sT == 0.f ? vscale(prod, sO) : blend(VV::ld(t), prod, sT, sO));
@@ -311,17 +317,36 @@ int mc_conv_local_pool(const float* images, float* target, int numImages, int nu
     return launch_status("mc_conv_local_pool");
 }
 
-int mc_conv_local_max_undo(const float* images, const float* maxGrads, const float* maxActs, float* target, int numImages,
-                           int numFilters, int imgSize, int subsX, int startX, int strideX, int outputsX,
-                           float scaleTargets, float scaleOutput, mcStream_t s) {
-    MC_REQUIRE(images && maxGrads && maxActs && target, "mc_conv_local_max_undo: null pointer");
-    MC_POOLARGS_OK("mc_conv_local_max_undo");
+static int max_undo_entry(const char* who, bool relu, const float* images, const float* maxGrads, const float* maxActs, float* target,
+                          int numImages, int numFilters, int imgSize, int subsX, int startX, int strideX, int outputsX,
+                          float scaleTargets, float scaleOutput, mcStream_t s) {
+    MC_REQUIRE(images && maxGrads && maxActs && target, "%s: null pointer", who);
+    MC_REQUIRE(numImages > 0 && numFilters > 0 && imgSize > 0 && subsX > 0 && strideX > 0 && outputsX > 0, "%s: non-positive dimension", who);
+    MC_REQUIRE((size_t)numFilters * imgSize * imgSize * numImages < (1ull << 31), "%s: tensor exceeds 32-bit indexing", who);
     const bool v = use_vec(numImages, {images, maxGrads, maxActs, target});
     const size_t items = (size_t)numFilters * imgSize * imgSize * (numImages / (v ? 4 : 1));
     dim3 g(grid_items(items)), b(TPB);
-    if (v) hipLaunchKernelGGL(k_max_undo<4>, g, b, 0, S(s), images, maxGrads, maxActs, target, numImages, numFilters, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput);
-    else hipLaunchKernelGGL(k_max_undo<1>, g, b, 0, S(s), images, maxGrads, maxActs, target, numImages, numFilters, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput);
-    return launch_status("mc_conv_local_max_undo");
+#define MC_MU(V, R) hipLaunchKernelGGL((k_max_undo<V, R>), g, b, 0, S(s), images, maxGrads, maxActs, target, numImages, numFilters, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput)
+    if (v && relu) MC_MU(4, true);
+    else if (v) MC_MU(4, false);
+    else if (relu) MC_MU(1, true);
+    else MC_MU(1, false);
+#undef MC_MU
+    return launch_status(who);
+}
+
+int mc_conv_local_max_undo(const float* images, const float* maxGrads, const float* maxActs, float* target, int numImages,
+                           int numFilters, int imgSize, int subsX, int startX, int strideX, int outputsX,
+                           float scaleTargets, float scaleOutput, mcStream_t s) {
+    return max_undo_entry("mc_conv_local_max_undo", false, images, maxGrads, maxActs, target, numImages, numFilters, imgSize, subsX,
+                          startX, strideX, outputsX, scaleTargets, scaleOutput, s);
+}
+
+int mc_conv_local_max_undo_relu_grad(const float* images, const float* maxGrads, const float* maxActs, float* target,
+                                     int numImages, int numFilters, int imgSize, int subsX, int startX, int strideX,
+                                     int outputsX, float scaleTargets, float scaleOutput, mcStream_t s) {
+    return max_undo_entry("mc_conv_local_max_undo_relu_grad", true, images, maxGrads, maxActs, target, numImages, numFilters, imgSize,
+                          subsX, startX, strideX, outputsX, scaleTargets, scaleOutput, s);
 }
 
 int mc_conv_local_avg_undo(const float* avgGrads, float* target, int numImages, int numFilters, int imgSize, int subsX,

@@ -4,6 +4,7 @@
 //   neuron "dropout" : reference PluginsSrc/include/extralayers.cuh:34-102
 // Exports the two plugin entry points of the reference (extralayers.cu:200-215).  The
 // cost.gsinlabel layer of the reference's plugin is not provided (no shipped config uses it).
+#include <stdlib.h>
 #include <iostream>
 
 #include "../runtime/convnet.h"
@@ -49,11 +50,18 @@ protected:
     void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE) override {
         const int N = numCases(), P = pixels(_prev[inpIdx]->getNumOutputs()), cols = P * N;
         const size_t wsb = mc_gemm_workspace_bytes(_in, cols, _out);
+        // opt-in: measured slower than the separate relu-gradient pass on the short-K cccp products (see FCLayer::bpropActs)
+        static const bool fuse = getenv("MC_FUSE_RELU_GRAD_GEMM") != nullptr;
+        const float* mask = (fuse && scaleTargets == 0.f) ? claimReluGradMask(inpIdx) : nullptr;
         for (int ch = 0; ch < _channels; ch++) {
             const float* W = _weights[inpIdx].getW() + (size_t)ch * _out * _in;
             const float* G = v.data() + (size_t)ch * _out * cols;
             float* dX = _prev[inpIdx]->getActsGrad().data() + (size_t)ch * _in * cols;
-            RT_MC(mc_gemm(W, G, dX, _in, cols, _out, 1, 0, _in, cols, cols, scaleTargets, 1.f, nullptr, MC_NEURON_NONE, wsb ? workspace(wsb) : nullptr, wsb, ST()));
+            if (mask)   // the input is a relu's output: its gradient mask goes into this product's store
+                RT_MC(mc_gemm_relu_grad(W, G, dX, _in, cols, _out, 1, 0, _in, cols, cols, 0.f, 1.f, mask + (size_t)ch * _in * cols, cols,
+                                        wsb ? workspace(wsb) : nullptr, wsb, ST()));
+            else
+                RT_MC(mc_gemm(W, G, dX, _in, cols, _out, 1, 0, _in, cols, cols, scaleTargets, 1.f, nullptr, MC_NEURON_NONE, wsb ? workspace(wsb) : nullptr, wsb, ST()));
         }
     }
 

@@ -206,7 +206,25 @@ void NeuronLayer::fpropActs(int, float, PASS_TYPE passType) {
     _neuron->activate(*_inputs[0], getActs(), passType);
 }
 
+bool NeuronLayer::canFuseGradMask() {
+    static const bool off = getenv("MC_NO_FUSE_RELU_GRAD") != nullptr;
+    // in place on the gradient side (the matrix the consumer writes IS the one this layer hands down), a
+    // single gradient producer (nothing to accumulate), and somebody below who wants the gradient
+    return !off && _neuron->isRelu() && _actsGradTarget == 0 && _numGradProducersNext == 1 && _prev[0]->isGradConsumer();
+}
+
+const float* Layer::claimReluGradMask(int inpIdx) {
+    NeuronLayer* nl = dynamic_cast<NeuronLayer*>(_prev[inpIdx]);
+    if (!nl || !nl->canFuseGradMask()) return nullptr;
+    nl->setGradMasked();
+    return nl->getActs().data();
+}
+
 void NeuronLayer::bpropActs(DevMat& v, int, float scaleTargets, PASS_TYPE passType) {
+    if (_gradMasked) {   // the layer above stored grad * (act > 0) straight into the shared gradient matrix
+        _gradMasked = false;
+        return;
+    }
     if (_fused) {   // the fused path never ran activate(); the output IS the input matrix
         DevMat& y = getActs();
         DevMat& tgt = _prev[0]->getActsGrad();
@@ -427,8 +445,17 @@ void FCLayer::fpropActs(int inpIdx, float scaleTargets, PASS_TYPE) {
 void FCLayer::bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE) {
     const int N = numCases(), in = _prev[inpIdx]->getNumOutputs(), out = _numOutputs;
     const size_t wsb = mc_gemm_workspace_bytes(in, N, out);
-    RT_MC(mc_gemm(_weights[inpIdx].getW(), v.data(), _prev[inpIdx]->getActsGrad().data(), in, N, out, 1, 0, in, N, N, scaleTargets, 1.f, nullptr,
-                  MC_NEURON_NONE, wsb ? workspace(wsb) : nullptr, wsb, ST()));
+    // Fusing the relu gradient mask of the layer below into this product's store is available
+    // (mc_gemm_relu_grad) but measured slower on MI355X than the separate pass: the epilogue's mask reads are
+    // exposed at the end of every short-K workgroup (NIN cccp1: +63 us against 48 us saved).  Opt-in only.
+    static const bool fuse = getenv("MC_FUSE_RELU_GRAD_GEMM") != nullptr;
+    const float* mask = (fuse && scaleTargets == 0.f) ? claimReluGradMask(inpIdx) : nullptr;
+    if (mask)
+        RT_MC(mc_gemm_relu_grad(_weights[inpIdx].getW(), v.data(), _prev[inpIdx]->getActsGrad().data(), in, N, out, 1, 0, in, N, N, 0.f, 1.f, mask, N,
+                                wsb ? workspace(wsb) : nullptr, wsb, ST()));
+    else
+        RT_MC(mc_gemm(_weights[inpIdx].getW(), v.data(), _prev[inpIdx]->getActsGrad().data(), in, N, out, 1, 0, in, N, N, scaleTargets, 1.f, nullptr,
+                      MC_NEURON_NONE, wsb ? workspace(wsb) : nullptr, wsb, ST()));
 }
 
 void FCLayer::bpropBiases(DevMat& v, PASS_TYPE passType) {
@@ -624,8 +651,13 @@ void MaxPoolLayer::fpropActs(int, float, PASS_TYPE) {
 }
 
 void MaxPoolLayer::bpropActs(DevMat& v, int, float scaleTargets, PASS_TYPE) {
-    RT_MC(mc_conv_local_max_undo(_prev[0]->getActs().data(), v.data(), getActs().data(), _prev[0]->getActsGrad().data(), numCases(), _channels, _imgSize,
-                                 _sizeX, _start, _stride, _outputsX, scaleTargets, 1.f, ST()));
+    const float* mask = scaleTargets == 0.f ? claimReluGradMask(0) : nullptr;   // == _prev[0]->getActs()
+    if (mask)
+        RT_MC(mc_conv_local_max_undo_relu_grad(mask, v.data(), getActs().data(), _prev[0]->getActsGrad().data(), numCases(), _channels, _imgSize,
+                                               _sizeX, _start, _stride, _outputsX, 0.f, 1.f, ST()));
+    else
+        RT_MC(mc_conv_local_max_undo(_prev[0]->getActs().data(), v.data(), getActs().data(), _prev[0]->getActsGrad().data(), numCases(), _channels,
+                                     _imgSize, _sizeX, _start, _stride, _outputsX, scaleTargets, 1.f, ST()));
 }
 
 // ==========================================================================================

@@ -157,6 +157,10 @@ protected:
     virtual void truncBwdActs();
     void fpropNext(PASS_TYPE passType);
     int numCases() const { return _numCases; }
+    // Backward fusion: when input i is a relu neuron layer that gets its gradient from this layer alone and
+    // passes it on in place, returns that relu's output (the mask for mc_*_relu_grad) and tells the neuron
+    // layer to skip its own pass over the gradient; otherwise nullptr.
+    const float* claimReluGradMask(int inpIdx);
 
     ConvNet* _convNet;
     std::vector<Layer*> _prev, _next;
@@ -178,12 +182,16 @@ public:
     // set by the producing layer when it already applied this (in-place relu) neuron in its epilogue
     void setFusedIntoProducer(bool f) { _fused = f; }
     bool inPlace() const { return _actsTarget == 0; }
+    // true when the consumer of this layer's output can apply the relu gradient mask itself
+    bool canFuseGradMask();
+    void setGradMasked() { _gradMasked = true; }
 
 protected:
     void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
     void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
     Neuron* _neuron;
     bool _fused = false;
+    bool _gradMasked = false;   // this pass's gradient already carries the relu mask (see claimReluGradMask)
 };
 
 class WeightLayer : public Layer {

@@ -29,6 +29,8 @@ _SIGS = {
     "mc_local_weight_acts": [c_fp, c_fp, c_fp] + [c_i] * 11 + [c_f, c_f, c_fp],
     "mc_conv_weight_acts_pick_partial_sum": [c_i] * 6,
     "mc_gemm": [c_fp, c_fp, c_fp] + [c_i] * 8 + [c_f, c_f, c_fp, c_i, c_fp, c_sz, c_fp],
+    "mc_gemm_relu_grad": [c_fp, c_fp, c_fp] + [c_i] * 8 + [c_f, c_f, c_fp, c_i, c_fp, c_sz, c_fp],
+    "mc_conv_local_max_undo_relu_grad": [c_fp] * 4 + [c_i] * 7 + [c_f, c_f, c_fp],
     "mc_conv_local_pool": [c_fp, c_fp] + [c_i] * 8 + [c_fp],
     "mc_conv_local_max_undo": [c_fp] * 4 + [c_i] * 7 + [c_f, c_f, c_fp],
     "mc_conv_local_avg_undo": [c_fp] * 2 + [c_i] * 7 + [c_f, c_f, c_fp],

@@ -108,6 +108,15 @@ size_t mc_gemm_workspace_bytes(int m, int n, int k);
 int mc_gemm(const float* A, const float* B, float* C, int m, int n, int k, int transA, int transB,
             int lda, int ldb, int ldc, float scaleTargets, float scaleOutput, const float* rowBias,
             int neuron, void* workspace, size_t workspaceBytes, mcStream_t stream);
+/* The same product with the gradient mask of a relu fused into the store: every written element whose
+ * reluActs(i, j) (row stride ldr) is not > 0 becomes 0.  Replaces the pair
+ * FCLayer/CCCPLayer::bpropActs (layer.cu:380-384, extralayers.cu:103-124) + ReluNeuron's gradient
+ * `actGrad * (act > 0)` (Kernel/include/layers/neuron.cuh:173-178) of the relu layer that feeds this
+ * layer, when that relu has no other gradient producer: one pass over the gradient instead of three. */
+int mc_gemm_relu_grad(const float* A, const float* B, float* C, int m, int n, int k, int transA,
+                      int transB, int lda, int ldb, int ldc, float scaleTargets, float scaleOutput,
+                      const float* reluActs, int ldr, void* workspace, size_t workspaceBytes,
+                      mcStream_t stream);
 
 /* ---------------- pooling ----------------
  * convLocalPool<MaxPooler|AvgPooler> (Kernel/include/conv/conv_util.cuh:335-524),
@@ -122,6 +131,13 @@ int mc_conv_local_max_undo(const float* images, const float* maxGrads, const flo
                            float* target, int numImages, int numFilters, int imgSize, int subsX,
                            int startX, int strideX, int outputsX, float scaleTargets,
                            float scaleOutput, mcStream_t stream);
+/* convLocalMaxUndo when `images` is the output of a relu layer with no other gradient producer: the relu's
+ * gradient mask (neuron.cuh:173-178: grad * (act > 0)) is applied to this call's contribution before it is
+ * stored, so the relu layer's own backward pass over the tensor is not needed. */
+int mc_conv_local_max_undo_relu_grad(const float* images, const float* maxGrads, const float* maxActs,
+                                     float* target, int numImages, int numFilters, int imgSize,
+                                     int subsX, int startX, int strideX, int outputsX,
+                                     float scaleTargets, float scaleOutput, mcStream_t stream);
 int mc_conv_local_avg_undo(const float* avgGrads, float* target, int numImages, int numFilters,
                            int imgSize, int subsX, int startX, int strideX, int outputsX,
                            float scaleTargets, float scaleOutput, mcStream_t stream);

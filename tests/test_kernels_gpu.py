@@ -386,3 +386,45 @@ def test_weights_update_spans_matches_per_tensor_update():
     np.testing.assert_allclose(host(dw), ew, rtol=2e-6, atol=1e-6)
     o, n = offs[3], sizes[3][0]
     assert np.array_equal(host(dw)[o:o + 64], w[o:o + 64]) and np.array_equal(host(di)[o:o + 64], inc[o:o + 64])
+
+
+@pytest.mark.parametrize("m_,n_,k_", [(192, 2048, 160), (96, 640, 10), (37, 53, 29), (64, 128, 4096)])
+def test_gemm_relu_grad_equals_gemm_then_relu_gradient(m_, n_, k_):
+    """mc_gemm_relu_grad == mc_gemm followed by the relu layer's gradient g * (y > 0), bit for bit
+    (CCCPLayer::bpropActs + neuron.cuh:173-178); y has zeros (relu output) and negative garbage is masked too."""
+    m = mc()
+    rng = np.random.default_rng(31)
+    A = rng.standard_normal((k_, m_)).astype(np.float32)          # transA: dX = W^T . G
+    B = rng.standard_normal((k_, n_)).astype(np.float32)
+    y = np.maximum(rng.standard_normal((m_, n_)), 0).astype(np.float32)
+    dA, dB, dy = dev(A), dev(B), dev(y)
+    wsb = m.lib().mc_gemm_workspace_bytes(m_, n_, k_)
+    ws = zeros(max(1, wsb // 4))
+    ref = nans(m_, n_)
+    m.call("mc_gemm", ptr(dA), ptr(dB), ptr(ref), m_, n_, k_, 1, 0, m_, n_, n_, 0.0, 1.0, None, m.NEURON_NONE, ptr(ws), wsb, None)
+    m.call("mc_neuron_input_grad", m.NEURONS["relu"], 0.0, 0.0, ptr(ref), ptr(dy), ptr(ref), 0, ref.numel(), None)
+    got = nans(m_, n_)
+    m.call("mc_gemm_relu_grad", ptr(dA), ptr(dB), ptr(got), m_, n_, k_, 1, 0, m_, n_, n_, 0.0, 1.0, ptr(dy), n_, ptr(ws), wsb, None)
+    assert np.array_equal(host(got), host(ref))
+    exp = G.matmul(A.T, B) * (y > 0)
+    assert relerr(host(got), exp) < TOL
+
+
+def test_max_undo_relu_grad_equals_undo_then_relu_gradient():
+    m = mc()
+    rng = np.random.default_rng(32)
+    for (N, C, S, size, start, stride) in ((128, 96, 32, 3, 0, 2), (6, 5, 7, 3, 0, 2), (16, 8, 8, 2, 1, 2)):
+        outX = int(np.ceil((S - start - size) / float(stride))) + 1
+        x = np.maximum(rng.standard_normal((C * S * S, N)), 0).astype(np.float32)     # relu output: zero plateaus
+        dx = dev(x)
+        y = nans(C * outX * outX, N)
+        m.call("mc_conv_local_pool", ptr(dx), ptr(y), N, C, S, size, start, stride, outX, m.POOL_MAX, None)
+        g = dev(rng.standard_normal((C * outX * outX, N)))
+        ref = nans(*x.shape)
+        m.call("mc_conv_local_max_undo", ptr(dx), ptr(g), ptr(y), ptr(ref), N, C, S, size, start, stride, outX, 0.0, 1.0, None)
+        m.call("mc_neuron_input_grad", m.NEURONS["relu"], 0.0, 0.0, ptr(ref), ptr(dx), ptr(ref), 0, ref.numel(), None)
+        got = nans(*x.shape)
+        m.call("mc_conv_local_max_undo_relu_grad", ptr(dx), ptr(g), ptr(y), ptr(got), N, C, S, size, start, stride, outX, 0.0, 1.0, None)
+        assert np.array_equal(host(got), host(ref))
+        e = G.max_undo(x, host(g), host(y), N, C, S, size, start, stride, outX) * (x > 0)
+        assert np.array_equal(host(got), e)
