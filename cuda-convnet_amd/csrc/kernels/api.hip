@@ -1,5 +1,6 @@
 // api.hip -- extern "C" entry points for the contraction kernels (conv / local / dense),
-// error reporting, device query, split-K reduction, and the unshared (local) layer kernels.
+// error reporting, device query and the split-K reduction.  The unshared (local) layers run on the same
+// fp32-MFMA engine as batched products (igemm.hip: one product per module forward, one per pixel backward).
 #include <stdlib.h>
 #include <string.h>
 #include "mc_common.h"
@@ -30,8 +31,8 @@ int num_cus() {
 
 // implemented in igemm.hip
 int conv_filter_acts_impl(const float*, const float*, float*, const float*, int, int, int, int, int, int, int, int, int, int,
-                          int, int, float, float, hipStream_t);
-int conv_img_acts_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int, int, float,
+                          int, int, int, float, float, hipStream_t);
+int conv_img_acts_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int, int, int, float,
                        float, hipStream_t);
 int conv_weight_acts_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int, int, int,
                           float, float, hipStream_t);
@@ -107,104 +108,6 @@ __global__ void __launch_bounds__(256) k_splitk_reduce_tall(const float4* __rest
     }
 }
 
-// ---------------------------------------------------------------------------------
-// Unshared (local) layers: per-module filter banks W[m][c][p][f]
-// (Kernel/src/conv/filter_acts.cu:100-102 with conv=false).  Weight-bandwidth bound and
-// tiny in flops at the BASELINE shapes; straightforward coalesced kernels, 4 images per lane.
-// ---------------------------------------------------------------------------------
-struct LG {
-    int N, C, H, W, F, fs, fp, pad, stride, MY, MX, M, fc, fpg, groups;
-};
-
-template <int V>
-__global__ void k_local_filter_acts(const float* __restrict__ images, const float* __restrict__ filters, float* targets,
-                                    LG g, float sT, float sO) {
-    const int nChunks = g.N / V;
-    const size_t total = (size_t)g.F * g.M * nChunks;
-    for (size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (size_t)gridDim.x * blockDim.x) {
-        const int row = (int)(item / nChunks);
-        const int n = (int)(item - (size_t)row * nChunks) * V;
-        const int f = row / g.M, m = row - f * g.M;
-        const int grp = f / g.fpg;
-        const int my = m / g.MX, mx = m - my * g.MX;
-        const int y0 = g.pad + my * g.stride, x0 = g.pad + mx * g.stride;
-        float acc[V];
-#pragma unroll
-        for (int u = 0; u < V; ++u) acc[u] = 0.f;
-        for (int c = 0; c < g.fc; ++c)
-            for (int fy = 0; fy < g.fs; ++fy) {
-                const int y = y0 + fy;
-                if (y < 0 || y >= g.H) continue;
-                for (int fx = 0; fx < g.fs; ++fx) {
-                    const int x = x0 + fx;
-                    if (x < 0 || x >= g.W) continue;
-                    const float w = filters[((size_t)(m * g.fc + c) * g.fp + fy * g.fs + fx) * g.F + f];
-                    const float* src = images + ((size_t)((grp * g.fc + c) * g.H + y) * g.W + x) * g.N + n;
-                    if (V == 4) {
-                        const float4 v = *reinterpret_cast<const float4*>(src);
-                        acc[0] += w * v.x; acc[1 % V] += w * v.y; acc[2 % V] += w * v.z; acc[3 % V] += w * v.w;
-                    } else {
-                        acc[0] += w * src[0];
-                    }
-                }
-            }
-        float* t = targets + (size_t)row * g.N + n;
-#pragma unroll
-        for (int u = 0; u < V; ++u) t[u] = (sT == 0.f ? 0.f : sT * t[u]) + sO * acc[u];
-    }
-}
-
-template <int V>
-__global__ void k_local_img_acts(const float* __restrict__ hidActs, const float* __restrict__ filters, float* targets,
-                                 LG g, float sT, float sO) {
-    const int nChunks = g.N / V;
-    const int imgPix = g.H * g.W;
-    const size_t total = (size_t)g.C * imgPix * nChunks;
-    for (size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (size_t)gridDim.x * blockDim.x) {
-        const int row = (int)(item / nChunks);
-        const int n = (int)(item - (size_t)row * nChunks) * V;
-        const int c = row / imgPix, px = row - c * imgPix;
-        const int y = px / g.W, x = px - y * g.W;
-        const int grp = c / g.fc, cl = c - grp * g.fc;
-        float acc[V];
-#pragma unroll
-        for (int u = 0; u < V; ++u) acc[u] = 0.f;
-        for (int my = 0; my < g.MY; ++my) {
-            const int fy = y - (g.pad + my * g.stride);
-            if (fy < 0 || fy >= g.fs) continue;
-            for (int mx = 0; mx < g.MX; ++mx) {
-                const int fx = x - (g.pad + mx * g.stride);
-                if (fx < 0 || fx >= g.fs) continue;
-                const int m = my * g.MX + mx;
-                const float* wrow = filters + ((size_t)(m * g.fc + cl) * g.fp + fy * g.fs + fx) * g.F;
-                for (int f = grp * g.fpg; f < (grp + 1) * g.fpg; ++f) {
-                    const float w = wrow[f];
-                    const float* src = hidActs + ((size_t)f * g.M + m) * g.N + n;
-                    if (V == 4) {
-                        const float4 v = *reinterpret_cast<const float4*>(src);
-                        acc[0] += w * v.x; acc[1 % V] += w * v.y; acc[2 % V] += w * v.z; acc[3 % V] += w * v.w;
-                    } else {
-                        acc[0] += w * src[0];
-                    }
-                }
-            }
-        }
-        float* t = targets + (size_t)row * g.N + n;
-#pragma unroll
-        for (int u = 0; u < V; ++u) t[u] = (sT == 0.f ? 0.f : sT * t[u]) + sO * acc[u];
-    }
-}
-
-int make_lg(LG& g, int N, int C, int H, int W, int F, int fs, int pad, int stride, int MY, int MX, int groups, const char* who) {
-    MC_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && F > 0 && fs > 0 && stride > 0 && MY > 0 && MX > 0 && groups > 0,
-               "%s: non-positive dimension", who);
-    MC_REQUIRE(pad <= 0, "%s: paddingStart must be <= 0 (got %d)", who, pad);
-    MC_REQUIRE(C % groups == 0 && F % groups == 0, "%s: channels and filters must be divisible by groups", who);
-    MC_REQUIRE((size_t)N * C * H * W < (1ull << 31) && (size_t)N * F * MY * MX < (1ull << 31), "%s: tensor exceeds 32-bit indexing", who);
-    g = LG{N, C, H, W, F, fs, fs * fs, pad, stride, MY, MX, MY * MX, C / groups, F / groups, groups};
-    return MC_OK;
-}
-
 inline int grid_items(size_t items) {
     const size_t want = (items + TPB - 1) / TPB;
     const size_t cap = (size_t)num_cus() * 16;
@@ -257,7 +160,7 @@ int mc_conv_filter_acts(const float* images, const float* filters, float* target
     MC_REQUIRE(images && filters && targets, "mc_conv_filter_acts: null pointer");
     return conv_filter_acts_impl(images, filters, targets, nullptr, MC_NEURON_NONE, numImages, numImgColors, imgSizeY,
                                  imgSizeX, numFilters, filterSize, paddingStart, moduleStride, numModulesY, numModulesX,
-                                 numGroups, scaleTargets, scaleOutput, S(s));
+                                 numGroups, 0, scaleTargets, scaleOutput, S(s));
 }
 
 int mc_conv_filter_acts_fused(const float* images, const float* filters, float* targets, const float* biases, int neuron,
@@ -267,7 +170,7 @@ int mc_conv_filter_acts_fused(const float* images, const float* filters, float* 
     MC_REQUIRE(images && filters && targets, "mc_conv_filter_acts_fused: null pointer");
     MC_REQUIRE(neuron == MC_NEURON_NONE || neuron == MC_NEURON_RELU, "mc_conv_filter_acts_fused: unknown neuron %d", neuron);
     return conv_filter_acts_impl(images, filters, targets, biases, neuron, numImages, numImgColors, imgSizeY, imgSizeX,
-                                 numFilters, filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups,
+                                 numFilters, filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 0,
                                  scaleTargets, scaleOutput, S(s));
 }
 
@@ -276,7 +179,7 @@ int mc_conv_img_acts(const float* hidActs, const float* filters, float* targets,
                      int numModulesY, int numModulesX, int numGroups, float scaleTargets, float scaleOutput, mcStream_t s) {
     MC_REQUIRE(hidActs && filters && targets, "mc_conv_img_acts: null pointer");
     return conv_img_acts_impl(hidActs, filters, targets, numImages, numImgColors, imgSizeY, imgSizeX, numFilters, filterSize,
-                              paddingStart, moduleStride, numModulesY, numModulesX, numGroups, scaleTargets, scaleOutput,
+                              paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 0, scaleTargets, scaleOutput,
                               S(s));
 }
 
@@ -323,30 +226,18 @@ int mc_local_filter_acts(const float* images, const float* filters, float* targe
                          int numModulesY, int numModulesX, int numGroups, float scaleTargets, float scaleOutput,
                          mcStream_t s) {
     MC_REQUIRE(images && filters && targets, "mc_local_filter_acts: null pointer");
-    LG g;
-    int rc = make_lg(g, numImages, numImgColors, imgSizeY, imgSizeX, numFilters, filterSize, paddingStart, moduleStride,
-                     numModulesY, numModulesX, numGroups, "mc_local_filter_acts");
-    if (rc) return rc;
-    const bool v = numImages % 4 == 0 && aligned16(images) && aligned16(targets);
-    const size_t items = (size_t)g.F * g.M * (g.N / (v ? 4 : 1));
-    if (v) hipLaunchKernelGGL(k_local_filter_acts<4>, dim3(grid_items(items)), dim3(TPB), 0, S(s), images, filters, targets, g, scaleTargets, scaleOutput);
-    else hipLaunchKernelGGL(k_local_filter_acts<1>, dim3(grid_items(items)), dim3(TPB), 0, S(s), images, filters, targets, g, scaleTargets, scaleOutput);
-    return launch_status("mc_local_filter_acts");
+    return conv_filter_acts_impl(images, filters, targets, nullptr, MC_NEURON_NONE, numImages, numImgColors, imgSizeY, imgSizeX,
+                                 numFilters, filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 1,
+                                 scaleTargets, scaleOutput, S(s));
 }
 
 int mc_local_img_acts(const float* hidActs, const float* filters, float* targets, int numImages, int numImgColors,
                       int imgSizeY, int imgSizeX, int numFilters, int filterSize, int paddingStart, int moduleStride,
                       int numModulesY, int numModulesX, int numGroups, float scaleTargets, float scaleOutput, mcStream_t s) {
     MC_REQUIRE(hidActs && filters && targets, "mc_local_img_acts: null pointer");
-    LG g;
-    int rc = make_lg(g, numImages, numImgColors, imgSizeY, imgSizeX, numFilters, filterSize, paddingStart, moduleStride,
-                     numModulesY, numModulesX, numGroups, "mc_local_img_acts");
-    if (rc) return rc;
-    const bool v = numImages % 4 == 0 && aligned16(hidActs) && aligned16(targets);
-    const size_t items = (size_t)g.C * g.H * g.W * (g.N / (v ? 4 : 1));
-    if (v) hipLaunchKernelGGL(k_local_img_acts<4>, dim3(grid_items(items)), dim3(TPB), 0, S(s), hidActs, filters, targets, g, scaleTargets, scaleOutput);
-    else hipLaunchKernelGGL(k_local_img_acts<1>, dim3(grid_items(items)), dim3(TPB), 0, S(s), hidActs, filters, targets, g, scaleTargets, scaleOutput);
-    return launch_status("mc_local_img_acts");
+    return conv_img_acts_impl(hidActs, filters, targets, numImages, numImgColors, imgSizeY, imgSizeX, numFilters, filterSize,
+                              paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 1, scaleTargets, scaleOutput,
+                              S(s));
 }
 
 size_t mc_gemm_workspace_bytes(int m, int n, int k) {

@@ -69,6 +69,8 @@ struct Dims {
     int kChunk;       // k extent of one chunk (multiple of 4 when a KC loader is vectorised)
     int groups;
     int xcdSwizzle;   // set by launch_cfg when gridDim.x % 8 == 0
+    int batches;      // independent products sharing one launch (unshared layers: one per module / pixel); >= 1
+    int colB;         // column offset of batch b in the B operand and in C: b * colB
 };
 
 struct Epi {
@@ -82,6 +84,7 @@ struct Epi {
     const float* mask;  // nullable: outputs whose mask element is not > 0 are written as 0 (relu gradient)
     int ldmask;
 };
+// (batch b of a batched launch writes columns [b * d.colB, b * d.colB + d.Ng) of C)
 
 // exact floor(a / d) for 0 <= a < 2^22 using a precomputed float reciprocal
 __device__ __forceinline__ int fdiv(int a, float inv) { return (int)(((float)a + 0.5f) * inv); }
@@ -96,14 +99,15 @@ struct MatP {
     int R;       // extent of the non-k axis (per group)
     int gStride; // offset added per group
     unsigned bytes;  // extent of the whole operand (buffer descriptor range: loads beyond it return 0)
+    int bStride; // offset added per batch (unshared layers: one filter bank per module)
 };
 
 // stored (K, R): element (k, x) at k*ld + x
 struct MatNatAddr {
     typedef MatP P;
     static constexpr bool KC = false;
-    __device__ static __forceinline__ bool addr(const P& p, const ConvG&, int g, int k, int x, int& off) {
-        off = g * p.gStride + k * p.ld + x;
+    __device__ static __forceinline__ bool addr(const P& p, const ConvG&, int g, int b, int k, int x, int& off) {
+        off = g * p.gStride + b * p.bStride + k * p.ld + x;
         return x < p.R;
     }
     __device__ static __forceinline__ const float* base(const P& p) { return p.p; }
@@ -112,8 +116,8 @@ struct MatNatAddr {
 struct MatKcAddr {
     typedef MatP P;
     static constexpr bool KC = true;
-    __device__ static __forceinline__ bool addr(const P& p, const ConvG&, int g, int k, int x, int& off) {
-        off = g * p.gStride + x * p.ld + k;
+    __device__ static __forceinline__ bool addr(const P& p, const ConvG&, int g, int b, int k, int x, int& off) {
+        off = g * p.gStride + b * p.bStride + x * p.ld + k;
         return x < p.R;
     }
     __device__ static __forceinline__ const float* base(const P& p) { return p.p; }
@@ -143,7 +147,7 @@ __device__ __forceinline__ bool patch_addr(const ConvG& cg, int g, int kc, int m
 struct PatchNatAddr {
     typedef ConvP P;
     static constexpr bool KC = false;
-    __device__ static __forceinline__ bool addr(const P& p, const ConvG& cg, int g, int k, int x, int& off) {
+    __device__ static __forceinline__ bool addr(const P& p, const ConvG& cg, int g, int b, int k, int x, int& off) {
         const int m = x / cg.N;  // column decode is loop invariant in the K loop: exact integer division
         const int n = x - m * cg.N;
         return patch_addr(cg, g, k, m, n, off) & (x < p.R);
@@ -154,7 +158,7 @@ struct PatchNatAddr {
 struct PatchKcAddr {
     typedef ConvP P;
     static constexpr bool KC = true;
-    __device__ static __forceinline__ bool addr(const P& p, const ConvG& cg, int g, int k, int x, int& off) {
+    __device__ static __forceinline__ bool addr(const P& p, const ConvG& cg, int g, int b, int k, int x, int& off) {
         const int m = fdiv(k, cg.inv_N);
         const int n = k - m * cg.N;
         const int xx = x < p.R ? x : 0;
@@ -166,7 +170,7 @@ struct PatchKcAddr {
 struct HidNatAddr {
     typedef ConvP P;
     static constexpr bool KC = false;
-    __device__ static __forceinline__ bool addr(const P& p, const ConvG& cg, int g, int k, int x, int& off) {
+    __device__ static __forceinline__ bool addr(const P& p, const ConvG& cg, int g, int b, int k, int x, int& off) {
         const int px = x / cg.N;  // loop invariant in the K loop
         const int n = x - px * cg.N;
         const int y = px / cg.W;
@@ -193,11 +197,28 @@ struct HidNatAddr {
 struct FiltTAddr {
     typedef ConvP P;
     static constexpr bool KC = true;
-    __device__ static __forceinline__ bool addr(const P& p, const ConvG& cg, int g, int k, int x, int& off) {
+    __device__ static __forceinline__ bool addr(const P& p, const ConvG& cg, int g, int b, int k, int x, int& off) {
         const int fpix = fdiv(k, cg.inv_fpg);
         const int fl = k - fpix * cg.fpg;
-        off = (x * cg.fp + fpix) * cg.F + g * cg.fpg + fl;
-        return x < p.R;
+        if (!cg.local) {
+            off = (x * cg.fp + fpix) * cg.F + g * cg.fpg + fl;
+            return x < p.R;
+        }
+        // unshared filters (img_acts.cu conv=false): batch b is the image pixel; tap fpix of that pixel belongs to
+        // the module whose window holds the pixel at that tap, and each module has its own filter bank
+        const int y = b / cg.W, xx = b - y * cg.W;
+        const int fy = fdiv(fpix, cg.inv_fs), fx = fpix - fy * cg.fs;
+        int ty = y - cg.pad - fy, tx = xx - cg.pad - fx;
+        bool ok = (ty >= 0) & (tx >= 0) & (x < p.R);
+        if (cg.stride != 1) {
+            const int my = ty / cg.stride, mx = tx / cg.stride;
+            ok &= (my * cg.stride == ty) & (mx * cg.stride == tx);
+            ty = my;
+            tx = mx;
+        }
+        ok &= (ty < cg.MY) & (tx < cg.MX);
+        off = (((ty * cg.MX + tx) * cg.fc + x) * cg.fp + fpix) * cg.F + g * cg.fpg + fl;
+        return ok;
     }
     __device__ static __forceinline__ const float* base(const P& p) { return p.p; }
 };
@@ -239,8 +260,8 @@ struct Loader {
         }
     }
 
-    __device__ __forceinline__ void fetch(__amdgpu_buffer_rsrc_t rs, const P& p, const ConvG& cg, int g, int k0, int kend, int x0,
-                                          int tid) {
+    __device__ __forceinline__ void fetch(__amdgpu_buffer_rsrc_t rs, const P& p, const ConvG& cg, int g, int b, int k0, int kend,
+                                          int x0, int xlim, int tid) {
 #ifdef MC_ABL_NOFETCH   // timing-only ablation builds (tools/build_variant.sh); wrong results
         if (k0 > 0) return;
 #endif
@@ -253,7 +274,7 @@ struct Loader {
             const int k = k0 + dk, x = x0 + dx;
             if (VEC == 4) {
                 int off;
-                const bool ok = ADDR::addr(p, cg, g, k, x, off) & (k < kend) & live;
+                const bool ok = ADDR::addr(p, cg, g, b, k, x, off) & (k < kend) & (x < xlim) & live;
                 const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)off * 4u : OOB, 0, 0);
                 r[it] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
             } else {
@@ -262,7 +283,7 @@ struct Loader {
                 for (int u = 0; u < 4; ++u) {
                     const int ku = KC ? k + u : k, xu = KC ? x : x + u;
                     int off;
-                    const bool ok = ADDR::addr(p, cg, g, ku, xu, off) & (ku < kend) & live;
+                    const bool ok = ADDR::addr(p, cg, g, b, ku, xu, off) & (ku < kend) & (xu < xlim) & live;
                     e[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, ok ? (unsigned)off * 4u : OOB, 0, 0));
                 }
                 r[it] = make_float4(e[0], e[1], e[2], e[3]);
@@ -301,6 +322,8 @@ __device__ __forceinline__ void lds_done_barrier() {
 // The kernel.  512 threads: waves 0-3 are consumers laid out WM x WN, wave tile (32*MT) x (32*NT);
 // waves 4-7 are producers (THREADS = 256 of them share the tile gather).
 // ---------------------------------------------------------------------------------
+// (Asking for more resident workgroups per CU through __launch_bounds__' second argument was measured: the
+// register cap spills in the k-contiguous loaders and no shape gets faster.)
 template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC, int NS>
 __global__ void __launch_bounds__(2 * THREADS)
 mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
@@ -319,8 +342,12 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     // round-robin over the 8 XCDs, so workgroup b -> tile (b % 8) * (gridDim.x / 8) + b / 8 keeps
     // neighbouring column tiles (neighbouring modules, overlapping patches) on one XCD's L2.
     const int bx = d.xcdSwizzle ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-    const int i0 = blockIdx.y * BM, j0 = bx * BN;
-    const int q = blockIdx.z / d.groups, g = blockIdx.z - q * d.groups;
+    // blockIdx.z = (k-chunk q, group g, batch b)
+    const int zb = blockIdx.z / d.batches, b = blockIdx.z - zb * d.batches;
+    const int q = zb / d.groups, g = zb - q * d.groups;
+    const int coff = b * d.colB;                      // first B / C column of this batch
+    const int i0 = blockIdx.y * BM, j0 = coff + bx * BN;
+    const int ilim = d.Mg, jlim = coff + d.Ng;
     const int kbeg = q * d.kChunk;
     const int kend = min(kbeg + d.kChunk, d.Kg);
     const int nk = (kend - kbeg + BK - 1) / BK;   // >= 1 K steps; barriers executed by every wave: 1 + nk
@@ -342,8 +369,8 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         LA as[NS];
         LB bs[NS];
         auto fetch = [&](auto& la, auto& lb, int u) {
-            la.fetch(ra, pa, cg, g, kbeg + u * BK, kend, i0, tid);
-            lb.fetch(rb, pb, cg, g, kbeg + u * BK, kend, j0, tid);
+            la.fetch(ra, pa, cg, g, b, kbeg + u * BK, kend, i0, ilim, tid);
+            lb.fetch(rb, pb, cg, g, b, kbeg + u * BK, kend, j0, jlim, tid);
         };
         auto commit = [&](const auto& la, const auto& lb, int stage) {
             la.commit(smem + stage * STAGE, tid);
@@ -518,7 +545,7 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = i0 + (wm * MT + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (i < d.Mg && j < d.Ng) {
+                if (i < ilim && j < jlim) {
                     const int row = i + g * ep.rowG;
                     const long idx = (long)row * ep.ldc + j + g * ep.colG;
                     float v = ep.alpha * acc[a][b][r];
@@ -551,7 +578,7 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    dim3 grid(ceil_div(d.Ng, BN), ceil_div(d.Mg, BM), chunks * d.groups);
+    dim3 grid(ceil_div(d.Ng, BN), ceil_div(d.Mg, BM), chunks * d.groups * d.batches);
     static const bool noswz = getenv("MC_IGEMM_NOSWZ") != nullptr;
     d.xcdSwizzle = (grid.x % 8 == 0 && grid.x >= 16 && !noswz) ? 1 : 0;
     if (grid.y > 65535 || grid.z > 65535) {
@@ -581,7 +608,7 @@ int launch_rows_cols(const typename AADDR::P& pa, const typename BADDR::P& pb, c
     // consumer wave) win almost everywhere; exactly 160 rows (NIN cccp1 / cccp2) take one 160-row tile so the
     // big operand is read once; 192-column tiles (2x2 waves, 3 strips each) are used when they cut the
     // padding of the column extent (F = 192 weight gradients: 256 -> 192).
-    const long z = (long)chunks * d.groups;
+    const long z = (long)chunks * d.groups * d.batches;
     const int mt32 = ceil_div(d.Mg, 32);
     const long colTiles = ceil_div(d.Ng, 128);
     if (mt32 == 5 && colTiles * z >= num_cus())
@@ -610,6 +637,7 @@ int make_convg(ConvG& cg, int N, int C, int H, int W, int F, int fs, int pad, in
     const long biggest = (long)N * (long)((long)C * H * W > (long)F * MY * MX ? (long)C * H * W : (long)F * MY * MX);
     MC_REQUIRE(biggest < (1L << 30), "%s: tensor with %ld elements exceeds the 4 GiB buffer-descriptor range", who, biggest);
     // fdiv() decodes the K index with a float reciprocal, exact below 2^22
+    MC_REQUIRE((long)MY * MX * (local ? (long)(C / groups) * fs * fs : 1) * F < (1L << 30), "%s: filter tensor exceeds the 4 GiB buffer-descriptor range", who);
     MC_REQUIRE((long)MY * MX * N < (1L << 22) && (long)(C / groups) * fs * fs < (1L << 22) && (long)fs * fs * (F / groups) < (1L << 22),
                "%s: modules*images, channels*taps and taps*filters must each be < 2^22", who);
     cg.N = N; cg.H = H; cg.W = W; cg.fc = C / groups; cg.fs = fs; cg.fp = fs * fs; cg.pad = pad; cg.stride = stride;
@@ -626,13 +654,15 @@ int make_convg(ConvG& cg, int N, int C, int H, int W, int F, int fs, int pad, in
 // =================================================================================
 int conv_filter_acts_impl(const float* images, const float* filters, float* targets, const float* biases, int neuron,
                           int N, int C, int H, int W, int F, int fs, int pad, int stride, int MY, int MX, int groups,
-                          float scaleTargets, float scaleOutput, hipStream_t st) {
+                          int local, float scaleTargets, float scaleOutput, hipStream_t st) {
     ConvG cg;
-    int rc = make_convg(cg, N, C, H, W, F, fs, pad, stride, MY, MX, groups, 0, "convFilterActs");
+    int rc = make_convg(cg, N, C, H, W, F, fs, pad, stride, MY, MX, groups, local, local ? "localFilterActs" : "convFilterActs");
     if (rc) return rc;
-    Dims d{cg.fpg, cg.M * N, cg.fc * cg.fp, cg.fc * cg.fp, groups, 0};
+    // shared filters: one product over all M*N columns.  Unshared (filter_acts.cu conv=false): M products in one
+    // launch, batch = module, each over its own N columns with its own filter bank W[m].
+    Dims d{cg.fpg, local ? N : cg.M * N, cg.fc * cg.fp, cg.fc * cg.fp, groups, 0, local ? cg.M : 1, local ? N : 0};
     Epi ep{targets, cg.M * N, cg.fpg, 0, 0, scaleOutput, scaleTargets, biases, neuron, nullptr, 0};
-    MatP pa{filters, F, cg.fpg, cg.fpg, (unsigned)((size_t)cg.fc * cg.fp * F * 4)};  // filters[k*F + g*fpg + f]
+    MatP pa{filters, F, cg.fpg, cg.fpg, (unsigned)((size_t)(local ? cg.M : 1) * cg.fc * cg.fp * F * 4), local ? cg.fc * cg.fp * F : 0};  // filters[k*F + g*fpg + f]
     ConvP pb{images, cg.M * N, (unsigned)((size_t)C * H * W * N * 4)};
     const bool vec = (N % 4 == 0) && (cg.fpg % 4 == 0) && (F % 4 == 0) && aligned16(images) && aligned16(filters);
     if (vec) return launch_rows_cols<MatNatAddr, PatchNatAddr, MC_BK, 4>(pa, pb, cg, d, ep, 1, st);
@@ -643,14 +673,16 @@ int conv_filter_acts_impl(const float* images, const float* filters, float* targ
 // conv bwd-data: C[c][(px,n)] ; Mg = fc, Ng = H*W*N, Kg = fp*fpg
 // =================================================================================
 int conv_img_acts_impl(const float* hidActs, const float* filters, float* targets, int N, int C, int H, int W, int F,
-                       int fs, int pad, int stride, int MY, int MX, int groups, float scaleTargets, float scaleOutput,
-                       hipStream_t st) {
+                       int fs, int pad, int stride, int MY, int MX, int groups, int local, float scaleTargets,
+                       float scaleOutput, hipStream_t st) {
     ConvG cg;
-    int rc = make_convg(cg, N, C, H, W, F, fs, pad, stride, MY, MX, groups, 0, "convImgActs");
+    int rc = make_convg(cg, N, C, H, W, F, fs, pad, stride, MY, MX, groups, local, local ? "localImgActs" : "convImgActs");
     if (rc) return rc;
-    Dims d{cg.fc, H * W * N, cg.fp * cg.fpg, cg.fp * cg.fpg, groups, 0};
+    // unshared (img_acts.cu conv=false): one product per image pixel (batch = pixel), whose A operand gathers, tap
+    // by tap, the filter bank of the module that sees the pixel at that tap (FiltTAddr)
+    Dims d{cg.fc, local ? N : H * W * N, cg.fp * cg.fpg, cg.fp * cg.fpg, groups, 0, local ? H * W : 1, local ? N : 0};
     Epi ep{targets, H * W * N, cg.fc, 0, 0, scaleOutput, scaleTargets, nullptr, MC_NEURON_NONE, nullptr, 0};
-    ConvP pa{filters, cg.fc, (unsigned)((size_t)cg.fc * cg.fp * F * 4)};
+    ConvP pa{filters, cg.fc, (unsigned)((size_t)(local ? cg.M : 1) * cg.fc * cg.fp * F * 4)};
     ConvP pb{hidActs, H * W * N, (unsigned)((size_t)F * cg.M * N * 4)};
     // group offset of the A operand rows: channel c of group g uses filter rows (cl*fp+p), columns g*fpg+fl
     const bool vec = (N % 4 == 0) && (cg.fpg % 4 == 0) && (F % 4 == 0) && aligned16(hidActs) && aligned16(filters);
@@ -670,10 +702,10 @@ int conv_weight_acts_impl(const float* images, const float* hidActs, float* targ
     if (partialSum <= 0) partialSum = cg.M;
     MC_REQUIRE(cg.M % partialSum == 0, "convWeightActs: partialSum (%d) must divide numModules (%d)", partialSum, cg.M);
     const int chunks = cg.M / partialSum;
-    Dims d{cg.fc * cg.fp, cg.fpg, cg.M * N, partialSum * N, groups, 0};
+    Dims d{cg.fc * cg.fp, cg.fpg, cg.M * N, partialSum * N, groups, 0, 1, 0};
     Epi ep{targets, F, 0, cg.fpg, (long)cg.fc * cg.fp * F, scaleOutput, scaleTargets, nullptr, MC_NEURON_NONE, nullptr, 0};
     ConvP pa{images, cg.fc * cg.fp, (unsigned)((size_t)C * H * W * N * 4)};
-    MatP pb{hidActs, cg.M * N, cg.fpg, cg.fpg * cg.M * N, (unsigned)((size_t)F * cg.M * N * 4)};  // hid[(g*fpg+f)*M*N + k]
+    MatP pb{hidActs, cg.M * N, cg.fpg, cg.fpg * cg.M * N, (unsigned)((size_t)F * cg.M * N * 4), 0};  // hid[(g*fpg+f)*M*N + k]
     const bool vec = (N % 4 == 0) && aligned16(images) && aligned16(hidActs);
     if (vec) return launch_rows_cols<PatchKcAddr, MatKcAddr, 32, 4>(pa, pb, cg, d, ep, chunks, st);
     return launch_rows_cols<PatchKcAddr, MatKcAddr, 32, 1>(pa, pb, cg, d, ep, chunks, st);
@@ -692,13 +724,13 @@ int gemm_impl(const float* A, const float* B, float* Cm, int m, int n, int k, in
         kChunk = (kChunk + 31) / 32 * 32;
         chunks = ceil_div(k, kChunk);
     }
-    Dims d{m, n, k, kChunk, 1, 0};
+    Dims d{m, n, k, kChunk, 1, 0, 1, 0};
     Epi ep{Cm, ldc, 0, 0, chunkStride, alpha, beta, rowBias, neuron, mask, ldmask};
     // operand extents in bytes: (rows - 1) * ld + row length
     const size_t ea = transA ? (size_t)(k - 1) * lda + m : (size_t)(m - 1) * lda + k;
     const size_t eb = transB ? (size_t)(n - 1) * ldb + k : (size_t)(k - 1) * ldb + n;
-    MatP pa{A, lda, m, 0, (unsigned)(ea * 4)};
-    MatP pb{B, ldb, n, 0, (unsigned)(eb * 4)};
+    MatP pa{A, lda, m, 0, (unsigned)(ea * 4), 0};
+    MatP pb{B, ldb, n, 0, (unsigned)(eb * 4), 0};
     const bool al = aligned16(A) && aligned16(B) && lda % 4 == 0 && ldb % 4 == 0;
     // vector loads need the contiguous extent of each operand to be a multiple of 4
     const bool va = transA ? (m % 4 == 0) : (k % 4 == 0);
