@@ -130,6 +130,141 @@ __global__ void k_max_undo(const float* __restrict__ imgs, const float* __restri
     }
 }
 
+// ------------------------------------------------------------------ 2-D mapped variants (vector path)
+// Same arithmetic as k_pool / k_max_undo, different work distribution: blockIdx.y = channel, a 256-thread
+// workgroup = LX image-chunk lanes x (256 / LX) columns, and every thread walks a band of rows.  No per-item
+// 64-bit divisions, x-side window bounds hoisted out of the row loop, 4-8 results per thread: the flat
+// kernels spend more issue slots on index arithmetic than on their 9 loads.
+struct Map2D {
+    int lxShift;   // log2(LX), LX = lanes along the image-chunk axis (<= 32)
+    int xBlocks;   // workgroups along x
+    int band;      // rows per thread
+};
+
+template <bool MAX>
+__global__ void __launch_bounds__(256) k_pool_2d(const float* __restrict__ imgs, float* target, int N, int imgSize, int subsX,
+                                                 int startX, int strideX, int outputsX, Map2D mp) {
+    typedef Vec<4> VV;
+    const int LX = 1 << mp.lxShift;
+    const int nl = threadIdx.x & (LX - 1), oxl = threadIdx.x >> mp.lxShift;
+    const int xb = blockIdx.x % mp.xBlocks, yb = blockIdx.x / mp.xBlocks;
+    const int ox = xb * (256 >> mp.lxShift) + oxl;
+    const int c = blockIdx.y;
+    if (ox >= outputsX) return;
+    const int sx = startX + ox * strideX;
+    const int x0 = max(0, sx), x1 = min(imgSize, sx + subsX);
+    const int numOut = outputsX * outputsX;
+    const int oyEnd = min(outputsX, (yb + 1) * mp.band);
+    const float* src = imgs + (size_t)c * imgSize * imgSize * N;
+    float* dst = target + (size_t)c * numOut * N;
+    for (int n = nl * 4; n < N; n += LX * 4)
+        for (int oy = yb * mp.band; oy < oyEnd; ++oy) {
+            const int sy = startX + oy * strideX;
+            const int y0 = max(0, sy), y1 = min(imgSize, sy + subsX);
+            float4 acc = VV::splat(MAX ? -2e38f : 0.f);
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) {
+                    const float4 v = VV::ld(src + (size_t)(y * imgSize + x) * N + n);
+                    acc = MAX ? vmax(acc, v) : vadd(acc, v);
+                }
+            if (!MAX) acc = vdivs(acc, (float)((y1 - y0) * (x1 - x0)));
+            VV::st(dst + (size_t)(oy * outputsX + ox) * N + n, acc);
+        }
+}
+
+template <bool RELU>
+__global__ void __launch_bounds__(256) k_max_undo_2d(const float* __restrict__ imgs, const float* __restrict__ maxGrads,
+                                                     const float* __restrict__ maxActs, float* target, int N, int imgSize, int subsX,
+                                                     int startX, int strideX, int outputsX, float sT, float sO, Map2D mp) {
+    typedef Vec<4> VV;
+    const int LX = 1 << mp.lxShift;
+    const int nl = threadIdx.x & (LX - 1), xl = threadIdx.x >> mp.lxShift;
+    const int xb = blockIdx.x % mp.xBlocks, yb = blockIdx.x / mp.xBlocks;
+    const int x = xb * (256 >> mp.lxShift) + xl;
+    const int c = blockIdx.y;
+    if (x >= imgSize) return;
+    const int numOut = outputsX * outputsX;
+    const int lim = startX + strideX * (outputsX - 1) + subsX;
+    const bool xin = x >= startX && x < lim;
+    int xlo = 0, xhi = 0;
+    if (xin) out_range(x, startX, subsX, strideX, outputsX, xlo, xhi);
+    const int yEnd = min(imgSize, (yb + 1) * mp.band);
+    const size_t ibase = (size_t)c * imgSize * imgSize * N, obase = (size_t)c * numOut * N;
+    for (int n = nl * 4; n < N; n += LX * 4)
+        for (int y = yb * mp.band; y < yEnd; ++y) {
+            const size_t e = ibase + (size_t)(y * imgSize + x) * N + n;
+            float4 prod = VV::splat(0.f);
+            if (xin && y >= startX && y < lim) {
+                int ylo, yhi;
+                out_range(y, startX, subsX, strideX, outputsX, ylo, yhi);
+                const float4 img = VV::ld(imgs + e);
+                for (int my = ylo; my < yhi; ++my)
+                    for (int mx = xlo; mx < xhi; ++mx) {
+                        const size_t o = obase + (size_t)(my * outputsX + mx) * N + n;
+                        prod = vadd(prod, veqmul(img, VV::ld(maxActs + o), VV::ld(maxGrads + o)));
+                    }
+                if (RELU) prod = vposmask(img, prod);
+            }
+            VV::st(target + e, sT == 0.f ? vscale(prod, sO) : blend(VV::ld(target + e), prod, sT, sO));
+        }
+}
+
+// rows: items along the walked axis, cols: items along x; channels on grid.y (<= 65535)
+inline Map2D make_map2d(int N, int rows, int cols, int C, dim3& grid) {
+    Map2D mp;
+    const int chunks = N / 4;
+    mp.lxShift = 0;
+    while ((1 << mp.lxShift) < chunks && mp.lxShift < 5) ++mp.lxShift;
+    const int colsPerBlock = 256 >> mp.lxShift;
+    mp.xBlocks = ceil_div(cols, colsPerBlock);
+    // rows per thread: 8 when that still leaves >= 4 workgroups per CU, else fewer
+    mp.band = 8;
+    while (mp.band > 1 && (long)mp.xBlocks * ceil_div(rows, mp.band) * C < 4L * num_cus()) mp.band >>= 1;
+    grid = dim3(mp.xBlocks * ceil_div(rows, mp.band), C, 1);
+    return mp;
+}
+
+// ------------------------------------------------------------------ large windows, few outputs (NIN's global 8x8 average)
+// One workgroup per (channel, output pixel): LX image-chunk lanes x (256 / LX) window slices; slice s takes window
+// elements s, s + S, ... and the S partial results are combined in slice order (deterministic).  The flat
+// kernel gives each of a few hundred threads the whole window: 64 dependent round trips.
+template <bool MAX>
+__global__ void __launch_bounds__(256) k_pool_bigwin(const float* __restrict__ imgs, float* target, int N, int imgSize, int subsX,
+                                                     int startX, int strideX, int outputsX, int lxShift) {
+    typedef Vec<4> VV;
+    __shared__ float4 part[256];
+    const int LX = 1 << lxShift, S = 256 >> lxShift;
+    const int nl = threadIdx.x & (LX - 1), sl = threadIdx.x >> lxShift;
+    const int o = blockIdx.x, c = blockIdx.y;
+    const int oy = o / outputsX, ox = o - oy * outputsX;
+    const int sy = startX + oy * strideX, sx = startX + ox * strideX;
+    const int y0 = max(0, sy), x0 = max(0, sx);
+    const int y1 = min(imgSize, sy + subsX), x1 = min(imgSize, sx + subsX);
+    const int wx = x1 - x0, cnt = (y1 - y0) * wx;
+    const float* src = imgs + (size_t)c * imgSize * imgSize * N;
+    for (int n0 = 0; n0 < N; n0 += LX * 4) {
+        const int n = n0 + nl * 4;
+        float4 acc = VV::splat(MAX ? -2e38f : 0.f);
+        if (n < N)
+            for (int e = sl; e < cnt; e += S) {
+                const int dy = e / wx, dx = e - dy * wx;
+                const float4 v = VV::ld(src + (size_t)((y0 + dy) * imgSize + x0 + dx) * N + n);
+                acc = MAX ? vmax(acc, v) : vadd(acc, v);
+            }
+        part[threadIdx.x] = acc;
+        __syncthreads();
+        if (sl == 0 && n < N) {
+            for (int k = 1; k < S; ++k) {
+                const float4 v = part[k * LX + nl];
+                acc = MAX ? vmax(acc, v) : vadd(acc, v);
+            }
+            if (!MAX) acc = vdivs(acc, (float)cnt);
+            VV::st(target + ((size_t)c * outputsX * outputsX + o) * N + n, acc);
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ avg-pool undo
 template <int V>
 __global__ void k_avg_undo(const float* __restrict__ avgGrads, float* target, int N, int C, int imgSize, int subsX,
@@ -308,6 +443,21 @@ int mc_conv_local_pool(const float* images, float* target, int numImages, int nu
     MC_POOLARGS_OK("mc_conv_local_pool");
     MC_REQUIRE(pooler == MC_POOL_MAX || pooler == MC_POOL_AVG, "mc_conv_local_pool: unknown pooler %d", pooler);
     const bool v = use_vec(numImages, {images, target});
+    if (v && numFilters <= 65535 && subsX * subsX >= 32 && (long)outputsX * outputsX * numFilters <= 8L * num_cus()) {
+        int lx = 0;
+        while ((1 << lx) < numImages / 4 && lx < 5) ++lx;
+        dim3 g2(outputsX * outputsX, numFilters, 1);
+        if (pooler == MC_POOL_MAX) hipLaunchKernelGGL(k_pool_bigwin<true>, g2, dim3(256), 0, S(s), images, target, numImages, imgSize, subsX, startX, strideX, outputsX, lx);
+        else hipLaunchKernelGGL(k_pool_bigwin<false>, g2, dim3(256), 0, S(s), images, target, numImages, imgSize, subsX, startX, strideX, outputsX, lx);
+        return launch_status("mc_conv_local_pool");
+    }
+    if (v && numFilters <= 65535) {
+        dim3 g2;
+        const Map2D mp = make_map2d(numImages, outputsX, outputsX, numFilters, g2);
+        if (pooler == MC_POOL_MAX) hipLaunchKernelGGL(k_pool_2d<true>, g2, dim3(256), 0, S(s), images, target, numImages, imgSize, subsX, startX, strideX, outputsX, mp);
+        else hipLaunchKernelGGL(k_pool_2d<false>, g2, dim3(256), 0, S(s), images, target, numImages, imgSize, subsX, startX, strideX, outputsX, mp);
+        return launch_status("mc_conv_local_pool");
+    }
     const size_t items = (size_t)numFilters * outputsX * outputsX * (numImages / (v ? 4 : 1));
     dim3 g(grid_items(items)), b(TPB);
 #define L(V, MAXP) hipLaunchKernelGGL((k_pool<V, MAXP>), g, b, 0, S(s), images, target, numImages, numFilters, imgSize, subsX, startX, strideX, outputsX)
@@ -324,6 +474,13 @@ static int max_undo_entry(const char* who, bool relu, const float* images, const
     MC_REQUIRE(numImages > 0 && numFilters > 0 && imgSize > 0 && subsX > 0 && strideX > 0 && outputsX > 0, "%s: non-positive dimension", who);
     MC_REQUIRE((size_t)numFilters * imgSize * imgSize * numImages < (1ull << 31), "%s: tensor exceeds 32-bit indexing", who);
     const bool v = use_vec(numImages, {images, maxGrads, maxActs, target});
+    if (v && numFilters <= 65535) {
+        dim3 g2;
+        const Map2D mp = make_map2d(numImages, imgSize, imgSize, numFilters, g2);
+        if (relu) hipLaunchKernelGGL(k_max_undo_2d<true>, g2, dim3(256), 0, S(s), images, maxGrads, maxActs, target, numImages, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput, mp);
+        else hipLaunchKernelGGL(k_max_undo_2d<false>, g2, dim3(256), 0, S(s), images, maxGrads, maxActs, target, numImages, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput, mp);
+        return launch_status(who);
+    }
     const size_t items = (size_t)numFilters * imgSize * imgSize * (numImages / (v ? 4 : 1));
     dim3 g(grid_items(items)), b(TPB);
 #define MC_MU(V, R) hipLaunchKernelGGL((k_max_undo<V, R>), g, b, 0, S(s), images, maxGrads, maxActs, target, numImages, numFilters, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput)

@@ -98,7 +98,10 @@ def test_hip_pool_norm_cost_match_pins():
         x, g = keep(dev(d["p%d_x" % i])), keep(dev(d["p%d_g" % i]))
         y = nans(*d["p%d_y" % i].shape)
         m.call("mc_conv_local_pool", ptr(x), ptr(y), N, C, S, size, start, stride, outX, m.POOL_MAX if is_max else m.POOL_AVG, None)
-        assert np.array_equal(host(y), d["p%d_y" % i])
+        if is_max:
+            assert np.array_equal(host(y), d["p%d_y" % i])
+        else:
+            np.testing.assert_allclose(host(y), d["p%d_y" % i], rtol=1e-6, atol=1e-6)
         t = nans(*d["p%d_d" % i].shape)
         if is_max:
             m.call("mc_conv_local_max_undo", ptr(x), ptr(g), ptr(y), ptr(t), N, C, S, size, start, stride, outX, 0.0, 1.0, None)

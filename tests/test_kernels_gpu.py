@@ -166,7 +166,10 @@ def test_pool_and_undo(N, C, S, size, start, stride, kind):
     y = nans(C * outX * outX, N)
     m.call("mc_conv_local_pool", ptr(dx), ptr(y), N, C, S, size, start, stride, outX, m.POOL_MAX if kind == "max" else m.POOL_AVG, None)
     ey = G.pool(x, N, C, S, size, start, stride, outX, kind)
-    assert np.array_equal(host(y), ey)            # bit exact (same fp32 order)
+    if kind == "max":
+        assert np.array_equal(host(y), ey)        # bit exact
+    else:                                         # large windows are summed in slices: order differs from the oracle's
+        np.testing.assert_allclose(host(y), ey, rtol=1e-6, atol=1e-6)
     g = rng.standard_normal(ey.shape).astype(np.float32)
     dg = dev(g)
     prev = rng.standard_normal(x.shape).astype(np.float32)
