@@ -28,6 +28,9 @@
 //     its own slab; the reference's partialSum layout is exactly that), groups are independent
 //     GEMMs on disjoint channel/filter ranges.
 #include <stdlib.h>
+#include <string.h>
+#include <map>
+#include <mutex>
 #include "mc_common.h"
 
 #ifdef MC_STAMP   // diagnostic build only (tools/build_variant.sh stamp -DMC_STAMP): where do the K steps spend their cycles?
@@ -48,6 +51,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int THREADS = 256;
 #ifndef MC_NS
 #define MC_NS 3    // tile register sets per producer thread (tiles in flight per workgroup)
+#endif
+#ifndef MC_BK_KC
+#define MC_BK_KC 32   // k extent of one LDS tile when both operands are k-contiguous (weight gradients)
 #endif
 #ifndef MC_BK
 #define MC_BK 16   // k extent of one LDS tile for the contractions whose operands are not both k-contiguous
@@ -591,38 +597,122 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
 
 // Tile choice.  The MFMA pipe is the bound (64 cycles per 32x32x2 per SIMD), so what matters is
 // (a) not padding the row dimension much, (b) enough workgroups to cover 256 CUs.
+// ---------------------------------------------------------------------------------
+// Tile choice.  Six workgroup tiles are instantiated; a static rule picks one from the extents, and --
+// because the best tile depends on things the rule cannot see (how many workgroups fit a CU at that
+// register / LDS footprint, how the K chunks tail off) -- the first idempotent call of every distinct shape
+// times all six on the caller's stream and remembers the winner (MIOpen-"find" style; off with
+// MC_IGEMM_AUTOTUNE=0, report with =2).  Every tile adds the k terms of an output element in the same
+// order, so the choice never changes a result bit; the split-K chunk count, which would, is not tuned.
+// ---------------------------------------------------------------------------------
+enum { T11, T21, T31, T51, T23, T32, NTILES };
+static const char* const kTileName[NTILES] = {"32x128", "64x128", "96x128", "160x128", "128x192", "192x128"};
+
+template <class AADDR, class BADDR, int BK, int VEC>
+int launch_tile(int tile, const typename AADDR::P& pa, const typename BADDR::P& pb, const ConvG& cg, const Dims& d, const Epi& ep,
+                int chunks, hipStream_t st) {
+    switch (tile) {
+        case T11: return launch_cfg<AADDR, BADDR, 1, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+        case T21: return launch_cfg<AADDR, BADDR, 2, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+        case T31: return launch_cfg<AADDR, BADDR, 3, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+        case T51: return launch_cfg<AADDR, BADDR, 5, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+        case T23: return launch_cfg<AADDR, BADDR, 2, 3, 2, 2, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+        default:  return launch_cfg<AADDR, BADDR, 3, 2, 2, 2, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+    }
+}
+
+// Static rule (measured on MI355X, tools/tile_sweep.py over the NIN shapes): 128-column tiles (one 32-column
+// strip per consumer wave) win almost everywhere; exactly 160 rows (NIN cccp1 / cccp2) take one 160-row tile so
+// the big operand is read once; 192-column tiles (2x2 waves, 3 strips each) when they cut the padding of the
+// column extent (F = 192 weight gradients: 256 -> 192).
+inline int heuristic_tile(const Dims& d, int chunks) {
+    const long z = (long)chunks * d.groups * d.batches;
+    const int mt32 = ceil_div(d.Mg, 32);
+    const long colTiles = ceil_div(d.Ng, 128);
+    if (mt32 == 5 && colTiles * z >= num_cus()) return T51;
+    const long pad128 = (long)ceil_div(d.Ng, 128) * 128, pad192 = (long)ceil_div(d.Ng, 192) * 192;
+    if (pad192 < pad128 && mt32 >= 4 && (long)ceil_div(d.Mg, 128) * ceil_div(d.Ng, 192) * z >= num_cus() / 2) return T23;
+    // rows: the largest of {96, 64, 32} that divides the 32-padded row count, shrunk while the grid would leave CUs idle
+    int MTsel = (mt32 % 3 == 0) ? 3 : (mt32 % 2 == 0 || mt32 >= 8) ? 2 : 1;
+    while (MTsel > 1 && (long)ceil_div(d.Mg, 32 * MTsel) * colTiles * z < num_cus()) --MTsel;
+    return MTsel == 3 ? T31 : MTsel == 2 ? T21 : T11;
+}
+
+struct TuneKey {
+    const void* kind;   // one per (loaders, BK, VEC) instantiation
+    int v[20];
+    bool operator<(const TuneKey& o) const { return kind != o.kind ? kind < o.kind : memcmp(v, o.v, sizeof(v)) < 0; }
+};
+static std::map<TuneKey, int> g_tuned;
+static std::mutex g_tuneMu;
+
 template <class AADDR, class BADDR, int BK, int VEC>
 int launch_rows_cols(const typename AADDR::P& pa, const typename BADDR::P& pb, const ConvG& cg, const Dims& d,
                      const Epi& ep, int chunks, hipStream_t st) {
     // tuning knob (benchmarks only): MC_IGEMM_TILE="MT,NT" forces the wave tile
     static const char* forced = getenv("MC_IGEMM_TILE");
     if (forced && forced[0] && forced[1] == ',') {
-        const int fm = forced[0] - '0', fn = forced[2] - '0';
-#define MC_FORCE(a, b) if (fm == a && fn == b) return launch_cfg<AADDR, BADDR, a, b, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
-        MC_FORCE(1, 1) MC_FORCE(2, 1) MC_FORCE(3, 1) MC_FORCE(5, 1)
-#undef MC_FORCE
-        if (fm == 2 && fn == 3) return launch_cfg<AADDR, BADDR, 2, 3, 2, 2, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
-        if (fm == 3 && fn == 2) return launch_cfg<AADDR, BADDR, 3, 2, 2, 2, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+        static const int map[6][3] = {{1, 1, T11}, {2, 1, T21}, {3, 1, T31}, {5, 1, T51}, {2, 3, T23}, {3, 2, T32}};
+        for (auto& m : map)
+            if (forced[0] - '0' == m[0] && forced[2] - '0' == m[1]) return launch_tile<AADDR, BADDR, BK, VEC>(m[2], pa, pb, cg, d, ep, chunks, st);
     }
-    // Measured on MI355X (tools/tile_sweep.py over the NIN shapes): 128-column tiles (one 32-column strip per
-    // consumer wave) win almost everywhere; exactly 160 rows (NIN cccp1 / cccp2) take one 160-row tile so the
-    // big operand is read once; 192-column tiles (2x2 waves, 3 strips each) are used when they cut the
-    // padding of the column extent (F = 192 weight gradients: 256 -> 192).
-    const long z = (long)chunks * d.groups * d.batches;
-    const int mt32 = ceil_div(d.Mg, 32);
-    const long colTiles = ceil_div(d.Ng, 128);
-    if (mt32 == 5 && colTiles * z >= num_cus())
-        return launch_cfg<AADDR, BADDR, 5, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
-    const long pad128 = (long)ceil_div(d.Ng, 128) * 128, pad192 = (long)ceil_div(d.Ng, 192) * 192;
-    if (pad192 < pad128 && mt32 >= 4 && (long)ceil_div(d.Mg, 128) * ceil_div(d.Ng, 192) * z >= num_cus())
-        return launch_cfg<AADDR, BADDR, 2, 3, 2, 2, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
-    // rows: the largest of {96, 64, 32} that divides the 32-padded row count, shrunk while the grid
-    // would leave CUs idle
-    int MTsel = (mt32 % 3 == 0) ? 3 : (mt32 % 2 == 0 || mt32 >= 8) ? 2 : 1;
-    while (MTsel > 1 && (long)ceil_div(d.Mg, 32 * MTsel) * colTiles * z < num_cus()) --MTsel;
-    if (MTsel == 3) return launch_cfg<AADDR, BADDR, 3, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
-    if (MTsel == 2) return launch_cfg<AADDR, BADDR, 2, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
-    return launch_cfg<AADDR, BADDR, 1, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+    const int rule = heuristic_tile(d, chunks);
+    static const char* at = getenv("MC_IGEMM_AUTOTUNE");
+    static const int mode = at ? atoi(at) : 1;
+    if (mode == 0) return launch_tile<AADDR, BADDR, BK, VEC>(rule, pa, pb, cg, d, ep, chunks, st);
+
+    static char kindTag;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    TuneKey key;
+    key.kind = &kindTag;
+    const int vals[20] = {d.Mg, d.Ng, d.Kg, d.kChunk, d.groups, d.batches, d.colB, chunks, cg.N, cg.H, cg.W, cg.fc, cg.fs, cg.pad,
+                          cg.stride, cg.MY, cg.MX, cg.F, cg.local, dev};
+    memcpy(key.v, vals, sizeof(vals));
+    {
+        std::lock_guard<std::mutex> lk(g_tuneMu);
+        auto it = g_tuned.find(key);
+        if (it != g_tuned.end()) return launch_tile<AADDR, BADDR, BK, VEC>(it->second, pa, pb, cg, d, ep, chunks, st);
+    }
+    // an accumulating call (scaleTargets != 0) is not idempotent: serve it by the rule and let a later plain call tune
+    if (ep.beta != 0.f) return launch_tile<AADDR, BADDR, BK, VEC>(rule, pa, pb, cg, d, ep, chunks, st);
+
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        return launch_tile<AADDR, BADDR, BK, VEC>(rule, pa, pb, cg, d, ep, chunks, st);
+    int best = rule;
+    float bestMs = 1e30f, ms[NTILES];
+    for (int t = 0; t < NTILES; ++t) {
+        ms[t] = -1.f;
+        // skip tiles that would compute more than 4x the needed rows (a 160-row tile for a 10-row product)
+        static const int rowsOf[NTILES] = {32, 64, 96, 160, 128, 192};
+        if (t != rule && (long)ceil_div(d.Mg, rowsOf[t]) * rowsOf[t] > 4L * ((d.Mg + 31) / 32 * 32)) continue;
+        int rc = launch_tile<AADDR, BADDR, BK, VEC>(t, pa, pb, cg, d, ep, chunks, st);   // warm (and validates the launch)
+        if (rc != MC_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
+        (void)hipEventRecord(e0, st);
+        for (int r = 0; r < 2; ++r) (void)launch_tile<AADDR, BADDR, BK, VEC>(t, pa, pb, cg, d, ep, chunks, st);
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) continue;
+        float el = 0.f;
+        if (hipEventElapsedTime(&el, e0, e1) != hipSuccess) continue;
+        ms[t] = el * 0.5f;
+        if (ms[t] < bestMs) { bestMs = ms[t]; best = t; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (mode >= 2) {
+        fprintf(stderr, "[mc_igemm autotune] %s rows %d cols %d k %d chunks %d batches %d:",
+                AADDR::KC ? (BADDR::KC ? "kc/kc" : "kc/nat") : (BADDR::KC ? "nat/kc" : "nat/nat"),
+                d.Mg, d.Ng, d.Kg, chunks, d.batches);
+        for (int t = 0; t < NTILES; ++t)
+            if (ms[t] >= 0.f) fprintf(stderr, " %s=%.1fus%s", kTileName[t], ms[t] * 1e3f, t == best ? "*" : (t == rule ? "(rule)" : ""));
+        fprintf(stderr, "\n");
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_tuneMu);
+        g_tuned[key] = best;
+    }
+    return MC_OK;   // the timed launches already produced the result (identical for every tile)
 }
 
 inline float finv(int d) { return 1.0f / (float)d; }
@@ -707,8 +797,8 @@ int conv_weight_acts_impl(const float* images, const float* hidActs, float* targ
     ConvP pa{images, cg.fc * cg.fp, (unsigned)((size_t)C * H * W * N * 4)};
     MatP pb{hidActs, cg.M * N, cg.fpg, cg.fpg * cg.M * N, (unsigned)((size_t)F * cg.M * N * 4), 0};  // hid[(g*fpg+f)*M*N + k]
     const bool vec = (N % 4 == 0) && aligned16(images) && aligned16(hidActs);
-    if (vec) return launch_rows_cols<PatchKcAddr, MatKcAddr, 32, 4>(pa, pb, cg, d, ep, chunks, st);
-    return launch_rows_cols<PatchKcAddr, MatKcAddr, 32, 1>(pa, pb, cg, d, ep, chunks, st);
+    if (vec) return launch_rows_cols<PatchKcAddr, MatKcAddr, MC_BK_KC, 4>(pa, pb, cg, d, ep, chunks, st);
+    return launch_rows_cols<PatchKcAddr, MatKcAddr, MC_BK_KC, 1>(pa, pb, cg, d, ep, chunks, st);
 }
 
 // =================================================================================
@@ -742,8 +832,8 @@ int gemm_impl(const float* A, const float* B, float* Cm, int m, int n, int k, in
     if (transA && !transB) return MC_GEMM_CASE(MatNatAddr, MatNatAddr);
     if (!transA && !transB) return MC_GEMM_CASE(MatKcAddr, MatNatAddr);
     if (!transA && transB)
-        return vec ? launch_rows_cols<MatKcAddr, MatKcAddr, 32, 4>(pa, pb, cg, d, ep, chunks, st)
-                   : launch_rows_cols<MatKcAddr, MatKcAddr, 32, 1>(pa, pb, cg, d, ep, chunks, st);
+        return vec ? launch_rows_cols<MatKcAddr, MatKcAddr, MC_BK_KC, 4>(pa, pb, cg, d, ep, chunks, st)
+                   : launch_rows_cols<MatKcAddr, MatKcAddr, MC_BK_KC, 1>(pa, pb, cg, d, ep, chunks, st);
     return MC_GEMM_CASE(MatNatAddr, MatKcAddr);
 #undef MC_GEMM_CASE
 }
