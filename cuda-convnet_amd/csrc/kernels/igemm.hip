@@ -67,7 +67,7 @@ struct ConvG {
     int MY, MX, M;    // modules
     int F, fpg;       // numFilters, filters per group
     int local;        // unshared filters (leading module index)
-    float inv_fp, inv_fs, inv_fpg, inv_N, inv_MX, inv_W;
+    float inv_fp, inv_fs, inv_fpg, inv_N, inv_MX, inv_W, inv_stride;
 };
 
 struct Dims {
@@ -187,14 +187,36 @@ struct HidNatAddr {
         const int fx = fpix - fy * cg.fs;
         int ty = y - cg.pad - fy, tx = xx - cg.pad - fx;
         bool ok = (ty >= 0) & (tx >= 0) & (x < p.R);
-        if (cg.stride != 1) {
-            const int my = ty / cg.stride, mx = tx / cg.stride;
+        if (cg.stride != 1) {   // exact for 0 <= t < 2^22 (fdiv); negative t is already rejected by ok
+            const int my = fdiv(max(ty, 0), cg.inv_stride), mx = fdiv(max(tx, 0), cg.inv_stride);
             ok &= (my * cg.stride == ty) & (mx * cg.stride == tx);
             ty = my;
             tx = mx;
         }
         ok &= (ty < cg.MY) & (tx < cg.MX);
         off = ((g * cg.fpg + fl) * cg.M + ty * cg.MX + tx) * cg.N + n;
+        return ok;
+    }
+    __device__ static __forceinline__ const float* base(const P& p) { return p.p; }
+};
+// the same operand for moduleStride == 1 (every BASELINE layer that back-propagates to its input): no stride
+// division at all, 24-bit multiplies, range checks as unsigned compares -- the gather address arithmetic is what
+// bounds the producer waves of the backward-data product
+struct HidNatS1Addr {
+    typedef ConvP P;
+    static constexpr bool KC = false;
+    __device__ static __forceinline__ bool addr(const P& p, const ConvG& cg, int g, int b, int k, int x, int& off) {
+        const int px = x / cg.N;  // loop invariant in the K loop
+        const int n = x - px * cg.N;
+        const int y = px / cg.W;
+        const int xx = px - y * cg.W;
+        const int fpix = fdiv(k, cg.inv_fpg);
+        const int fl = k - __mul24(fpix, cg.fpg);
+        const int fy = fdiv(fpix, cg.inv_fs);
+        const int fx = fpix - __mul24(fy, cg.fs);
+        const int ty = y - cg.pad - fy, tx = xx - cg.pad - fx;
+        const bool ok = ((unsigned)ty < (unsigned)cg.MY) & ((unsigned)tx < (unsigned)cg.MX) & (x < p.R);
+        off = (__mul24(g * cg.fpg + fl, cg.M) + __mul24(ty, cg.MX) + tx) * cg.N + n;
         return ok;
     }
     __device__ static __forceinline__ const float* base(const P& p) { return p.p; }
@@ -217,7 +239,7 @@ struct FiltTAddr {
         int ty = y - cg.pad - fy, tx = xx - cg.pad - fx;
         bool ok = (ty >= 0) & (tx >= 0) & (x < p.R);
         if (cg.stride != 1) {
-            const int my = ty / cg.stride, mx = tx / cg.stride;
+            const int my = fdiv(max(ty, 0), cg.inv_stride), mx = fdiv(max(tx, 0), cg.inv_stride);
             ok &= (my * cg.stride == ty) & (mx * cg.stride == tx);
             ty = my;
             tx = mx;
@@ -734,6 +756,7 @@ int make_convg(ConvG& cg, int N, int C, int H, int W, int F, int fs, int pad, in
     cg.MY = MY; cg.MX = MX; cg.M = MY * MX; cg.F = F; cg.fpg = F / groups; cg.local = local;
     cg.inv_fp = finv(cg.fp); cg.inv_fs = finv(fs); cg.inv_fpg = finv(cg.fpg); cg.inv_N = finv(N); cg.inv_MX = finv(MX);
     cg.inv_W = finv(W);
+    cg.inv_stride = finv(stride);
     return MC_OK;
 }
 
@@ -776,6 +799,12 @@ int conv_img_acts_impl(const float* hidActs, const float* filters, float* target
     ConvP pb{hidActs, H * W * N, (unsigned)((size_t)F * cg.M * N * 4)};
     // group offset of the A operand rows: channel c of group g uses filter rows (cl*fp+p), columns g*fpg+fl
     const bool vec = (N % 4 == 0) && (cg.fpg % 4 == 0) && (F % 4 == 0) && aligned16(hidActs) && aligned16(filters);
+    if (stride == 1 && groups == 1 && !local) {
+        // with one group the transposed-filter operand is a plain k-contiguous matrix: row c, k = p*F + f at c*fp*F + k
+        MatP pm{filters, cg.fp * F, cg.fc, 0, pa.bytes, 0};
+        if (vec) return launch_rows_cols<MatKcAddr, HidNatS1Addr, MC_BK, 4>(pm, pb, cg, d, ep, 1, st);
+        return launch_rows_cols<MatKcAddr, HidNatS1Addr, MC_BK, 1>(pm, pb, cg, d, ep, 1, st);
+    }
     if (vec) return launch_rows_cols<FiltTAddr, HidNatAddr, MC_BK, 4>(pa, pb, cg, d, ep, 1, st);
     return launch_rows_cols<FiltTAddr, HidNatAddr, MC_BK, 1>(pa, pb, cg, d, ep, 1, st);
 }
