@@ -30,6 +30,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <map>
+#include <type_traits>
 #include <mutex>
 #include "mc_common.h"
 
@@ -67,6 +68,7 @@ struct ConvG {
     int MY, MX, M;    // modules
     int F, fpg;       // numFilters, filters per group
     int local;        // unshared filters (leading module index)
+    int kcUniform;    // weight gradient: every K tile lies inside one module (numImages % BK == 0, chunks start on a tile)
     float inv_fp, inv_fs, inv_fpg, inv_N, inv_MX, inv_W, inv_stride;
 };
 
@@ -164,6 +166,29 @@ struct PatchNatAddr {
 struct PatchKcAddr {
     typedef ConvP P;
     static constexpr bool KC = true;
+    // When a K tile (k = module * N + image) never straddles two modules, everything that depends on the module
+    // is the same for the whole tile: computed once from the tile's first k (workgroup-uniform), it leaves the
+    // per-element work at two adds and two range checks.  The row's own (channel, tap) decode does not depend
+    // on k at all and is hoisted out of the K loop by the compiler.
+    struct Tile { int y0, x0, base; };
+    __device__ static __forceinline__ Tile tile(const ConvG& cg, int k0) {
+        const int m = fdiv(k0, cg.inv_N);
+        const int my = fdiv(m, cg.inv_MX), mx = m - my * cg.MX;
+        Tile t;
+        t.y0 = cg.pad + my * cg.stride;
+        t.x0 = cg.pad + mx * cg.stride;
+        t.base = (t.y0 * cg.W + t.x0) * cg.N + (k0 - m * cg.N);
+        return t;
+    }
+    __device__ static __forceinline__ bool addr_in_tile(const P& p, const ConvG& cg, int g, const Tile& t, int dk, int x, int& off) {
+        const int xx = x < p.R ? x : 0;
+        const int c = fdiv(xx, cg.inv_fp);
+        const int pp = xx - c * cg.fp;
+        const int fy = fdiv(pp, cg.inv_fs);
+        const int fx = pp - fy * cg.fs;
+        off = (((g * cg.fc + c) * cg.H + fy) * cg.W + fx) * cg.N + t.base + dk;
+        return ((unsigned)(t.y0 + fy) < (unsigned)cg.H) & ((unsigned)(t.x0 + fx) < (unsigned)cg.W) & (x < p.R);
+    }
     __device__ static __forceinline__ bool addr(const P& p, const ConvG& cg, int g, int b, int k, int x, int& off) {
         const int m = fdiv(k, cg.inv_N);
         const int n = k - m * cg.N;
@@ -293,6 +318,35 @@ struct Loader {
 #ifdef MC_ABL_NOFETCH   // timing-only ablation builds (tools/build_variant.sh); wrong results
         if (k0 > 0) return;
 #endif
+        if constexpr (std::is_same<ADDR, PatchKcAddr>::value) {
+            if (cg.kcUniform) {   // workgroup-uniform branch
+                const PatchKcAddr::Tile t = PatchKcAddr::tile(cg, k0);
+#pragma unroll
+                for (int it = 0; it < NCH; ++it) {
+                    const int c = tid + it * THREADS;
+                    const bool live = CHUNKS % THREADS == 0 || c < CHUNKS;
+                    int dk, dx;
+                    chunk_pos(c, dk, dx);
+                    const int k = k0 + dk, x = x0 + dx;
+                    if (VEC == 4) {
+                        int off;
+                        const bool ok = PatchKcAddr::addr_in_tile(p, cg, g, t, dk, x, off) & (k < kend) & (x < xlim) & live;
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)off * 4u : OOB, 0, 0);
+                        r[it] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+                    } else {
+                        float e[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            int off;
+                            const bool ok = PatchKcAddr::addr_in_tile(p, cg, g, t, dk + u, x, off) & (k + u < kend) & (x < xlim) & live;
+                            e[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, ok ? (unsigned)off * 4u : OOB, 0, 0));
+                        }
+                        r[it] = make_float4(e[0], e[1], e[2], e[3]);
+                    }
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int it = 0; it < NCH; ++it) {
             const int c = tid + it * THREADS;
@@ -753,7 +807,7 @@ int make_convg(ConvG& cg, int N, int C, int H, int W, int F, int fs, int pad, in
     MC_REQUIRE((long)MY * MX * N < (1L << 22) && (long)(C / groups) * fs * fs < (1L << 22) && (long)fs * fs * (F / groups) < (1L << 22),
                "%s: modules*images, channels*taps and taps*filters must each be < 2^22", who);
     cg.N = N; cg.H = H; cg.W = W; cg.fc = C / groups; cg.fs = fs; cg.fp = fs * fs; cg.pad = pad; cg.stride = stride;
-    cg.MY = MY; cg.MX = MX; cg.M = MY * MX; cg.F = F; cg.fpg = F / groups; cg.local = local;
+    cg.MY = MY; cg.MX = MX; cg.M = MY * MX; cg.F = F; cg.fpg = F / groups; cg.local = local; cg.kcUniform = 0;
     cg.inv_fp = finv(cg.fp); cg.inv_fs = finv(fs); cg.inv_fpg = finv(cg.fpg); cg.inv_N = finv(N); cg.inv_MX = finv(MX);
     cg.inv_W = finv(W);
     cg.inv_stride = finv(stride);
@@ -818,6 +872,7 @@ int conv_weight_acts_impl(const float* images, const float* hidActs, float* targ
     ConvG cg;
     int rc = make_convg(cg, N, C, H, W, F, fs, pad, stride, MY, MX, groups, 0, "convWeightActs");
     if (rc) return rc;
+    cg.kcUniform = (N % MC_BK_KC == 0) ? 1 : 0;   // chunks start at multiples of partialSum * N, tiles at multiples of BK
     if (partialSum <= 0) partialSum = cg.M;
     MC_REQUIRE(cg.M % partialSum == 0, "convWeightActs: partialSum (%d) must divide numModules (%d)", partialSum, cg.M);
     const int chunks = cg.M / partialSum;

@@ -28,6 +28,21 @@ for _ in range(3): m.call("mc_conv_filter_acts", P(img), P(W), P(out), *geo, 0.0
 report("conv2 fwd", 512)
 for _ in range(3): m.call("mc_conv_img_acts", P(hid), P(W), P(din), *geo, 0.0, 1.0, None)
 report("conv2 bwd-data", 256)
+ps = m.lib().mc_conv_weight_acts_pick_partial_sum(N, C, F, fs, M * M, 1)
+tmp = torch.empty((M*M//ps)*C*fs*fs, F, device="cuda")
+for _ in range(3): m.call("mc_conv_weight_acts", P(img), P(hid), P(tmp), *geo, ps, 0.0, 1.0, None)
+report("conv2 wgrad ps=%d" % ps, 512)
+C3, H3, M3 = 192, 8, 8
+img3, W3, hid3 = R(C3*H3*H3, N), R(C3*9, 192), R(192*M3*M3, N)
+out3, din3 = torch.empty(192*M3*M3, N, device="cuda"), torch.empty(C3*H3*H3, N, device="cuda")
+geo3 = (N, C3, H3, H3, 192, 3, -1, 1, M3, M3, 1)
+for _ in range(3): m.call("mc_conv_filter_acts", P(img3), P(W3), P(out3), *geo3, 0.0, 1.0, None)
+report("conv3 fwd", 192)
+for _ in range(3): m.call("mc_conv_img_acts", P(hid3), P(W3), P(din3), *geo3, 0.0, 1.0, None)
+report("conv3 bwd-data", 192)
+Wc, xc, yc = R(160, 192), R(192, 1024 * N), torch.empty(160, 1024 * N, device="cuda")
+for _ in range(3): m.call("mc_gemm", P(Wc), P(xc), P(yc), 160, 1024 * N, 192, 0, 0, 192, 1024 * N, 1024 * N, 0.0, 1.0, None, 0, None, 0, None)
+report("cccp1 fwd 160x131072x192", 1024)
 A, B, Cm = R(2400, 192), R(2400, 32768), torch.empty(192, 32768, device="cuda")
 for _ in range(3): m.call("mc_gemm", P(A), P(B), P(Cm), 192, 32768, 2400, 1, 0, 192, 32768, 32768, 0.0, 1.0, None, 0, None, 0, None)
 report("gemm 192x32768x2400 tn", 512)
