@@ -34,8 +34,9 @@ int conv_filter_acts_impl(const float*, const float*, float*, const float*, int,
                           int, int, int, float, float, hipStream_t);
 int conv_img_acts_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int, int, int, float,
                        float, hipStream_t);
-int conv_weight_acts_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int, int, int,
+int conv_weight_acts_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int, int, int, int,
                           float, float, hipStream_t);
+int conv_weight_grad_plan(int, int, int, int, int, int, int*);
 int gemm_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, float, float, const float*, int,
               const float*, int, int, long, hipStream_t);
 
@@ -189,7 +190,7 @@ int mc_conv_weight_acts(const float* images, const float* hidActs, float* target
                         float scaleOutput, mcStream_t s) {
     MC_REQUIRE(images && hidActs && targets, "mc_conv_weight_acts: null pointer");
     return conv_weight_acts_impl(images, hidActs, targets, numImages, numImgColors, imgSizeY, imgSizeX, numFilters,
-                                 filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups, partialSum,
+                                 filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups, partialSum, 0,
                                  scaleTargets, scaleOutput, S(s));
 }
 
@@ -201,7 +202,7 @@ int mc_local_weight_acts(const float* images, const float* hidActs, float* targe
     // unshared weight gradient == shared one with partialSum = 1 (weight_acts.cu:1103-1108): every
     // module's chunk IS that module's filter bank.
     return conv_weight_acts_impl(images, hidActs, targets, numImages, numImgColors, imgSizeY, imgSizeX, numFilters,
-                                 filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 1,
+                                 filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 1, 0,
                                  scaleTargets, scaleOutput, S(s));
 }
 
@@ -292,6 +293,39 @@ int mc_gemm_relu_grad(const float* A, const float* B, float* C, int m, int n, in
     MC_REQUIRE(reluActs, "mc_gemm_relu_grad: null reluActs");
     return gemm_entry("mc_gemm_relu_grad", A, B, C, m, n, k, transA, transB, lda, ldb, ldc, scaleTargets, scaleOutput, nullptr,
                       MC_NEURON_NONE, reluActs, ldr, workspace, workspaceBytes, s);
+}
+
+size_t mc_conv_weight_grad_workspace_bytes(int numImages, int numImgColors, int numFilters, int filterSize, int numModules,
+                                           int numGroups) {
+    if (numImages <= 0 || numImgColors <= 0 || numFilters <= 0 || filterSize <= 0 || numModules <= 0 || numGroups <= 0) return 0;
+    int kc = 0;
+    const int chunks = conv_weight_grad_plan(numImages, numImgColors, numFilters, filterSize, numModules, numGroups, &kc);
+    return chunks > 1 ? (size_t)chunks * (numImgColors / numGroups) * filterSize * filterSize * numFilters * sizeof(float) : 0;
+}
+
+int mc_conv_weight_grad(const float* images, const float* hidActs, float* weightGrad, int numImages, int numImgColors,
+                        int imgSizeY, int imgSizeX, int numFilters, int filterSize, int paddingStart, int moduleStride,
+                        int numModulesY, int numModulesX, int numGroups, float scaleTargets, float scaleOutput,
+                        void* workspace, size_t workspaceBytes, mcStream_t s) {
+    MC_REQUIRE(images && hidActs && weightGrad, "mc_conv_weight_grad: null pointer");
+    MC_REQUIRE(numImages > 0 && numImgColors > 0 && numFilters > 0 && filterSize > 0 && numModulesY > 0 && numModulesX > 0 &&
+                   numGroups > 0 && numImgColors % numGroups == 0 && numFilters % numGroups == 0,
+               "mc_conv_weight_grad: bad dimensions");
+    const int M = numModulesY * numModulesX;
+    int kc = 0;
+    const int chunks = conv_weight_grad_plan(numImages, numImgColors, numFilters, filterSize, M, numGroups, &kc);
+    if (chunks <= 1)
+        return conv_weight_acts_impl(images, hidActs, weightGrad, numImages, numImgColors, imgSizeY, imgSizeX, numFilters, filterSize,
+                                     paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 0, 0, scaleTargets, scaleOutput,
+                                     S(s));
+    const size_t wel = (size_t)(numImgColors / numGroups) * filterSize * filterSize * numFilters;
+    MC_REQUIRE(workspace && aligned16(workspace) && workspaceBytes >= (size_t)chunks * wel * sizeof(float),
+               "mc_conv_weight_grad: workspace of %zu bytes needed (mc_conv_weight_grad_workspace_bytes)", (size_t)chunks * wel * sizeof(float));
+    float* slabs = static_cast<float*>(workspace);
+    int rc = conv_weight_acts_impl(images, hidActs, slabs, numImages, numImgColors, imgSizeY, imgSizeX, numFilters, filterSize,
+                                   paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 0, kc, 0.f, 1.f, S(s));
+    if (rc) return rc;
+    return mc_sum_cols(slabs, weightGrad, chunks, (int)wel, scaleTargets, scaleOutput, s);
 }
 
 }  // extern "C"

@@ -526,19 +526,13 @@ void ConvLayer::bpropBiases(DevMat& v, PASS_TYPE passType) {
 void ConvLayer::bpropWeights(DevMat& v, int i, PASS_TYPE passType) {
     // The reference sums `partialSum` modules per chunk into a temporary and then reduces the
     // chunks (layer.cu:503-523).  Same structure; the chunking is chosen for this device rather
-    // than read from the layer file (the sum is the same, only its association differs).
+    // than read from the layer file (the sum is the same, only its association differs), and the
+    // chunks need not be whole modules.
     const float scale = passType == PASS_GC ? 1.f : _weights[i].getEps() / _convNet->gradScaleCases(numCases());
     const float scaleTargets = _weights[i].getNumUpdates() > 0 ? 1.f : 0.f;
-    const int ps = mc_conv_weight_acts_pick_partial_sum(numCases(), _channels->at(i), _numFilters, _filterSize->at(i), _modules, _groups->at(i));
-    const int chunks = ps > 0 ? _modules / ps : 1;
-    const size_t welems = (size_t)_filterChannels->at(i) * _filterPixels->at(i) * _numFilters;
-    if (chunks <= 1) {
-        RT_MC(mc_conv_weight_acts(_prev[i]->getActs().data(), v.data(), _weights[i].getGrad(), CONV_GEOM(i), 0, scaleTargets, scale, ST()));
-        return;
-    }
-    float* tmp = workspace(welems * chunks * sizeof(float));
-    RT_MC(mc_conv_weight_acts(_prev[i]->getActs().data(), v.data(), tmp, CONV_GEOM(i), ps, 0.f, 1.f, ST()));
-    RT_MC(mc_sum_cols(tmp, _weights[i].getGrad(), chunks, (int)welems, scaleTargets, scale, ST()));
+    const size_t wsb = mc_conv_weight_grad_workspace_bytes(numCases(), _channels->at(i), _numFilters, _filterSize->at(i), _modules, _groups->at(i));
+    RT_MC(mc_conv_weight_grad(_prev[i]->getActs().data(), v.data(), _weights[i].getGrad(), CONV_GEOM(i), scaleTargets, scale,
+                              wsb ? workspace(wsb) : nullptr, wsb, ST()));
 }
 
 void ConvLayer::bpropActs(DevMat& v, int i, float scaleTargets, PASS_TYPE) {

@@ -90,6 +90,19 @@ int mc_local_weight_acts(const float* images, const float* hidActs, float* targe
                          int numImgColors, int imgSizeY, int imgSizeX, int numFilters, int filterSize,
                          int paddingStart, int moduleStride, int numModulesY, int numModulesX,
                          int numGroups, float scaleTargets, float scaleOutput, mcStream_t stream);
+/* ConvLayer::bpropWeights as a whole (layer.cu:503-523): convWeightActs into chunks of the (module, image) axis
+ * followed by the reduction of the chunks, weightGrad = scaleTargets*weightGrad + scaleOutput * sum.  Unlike
+ * mc_conv_weight_acts the chunks need not hold whole modules: the library sizes them so the launch fills the
+ * device in one round (a function of the shape and the CU count only, so results are run-to-run identical).
+ * workspace: mc_conv_weight_grad_workspace_bytes(...) bytes (0 = none needed), 16-byte aligned. */
+size_t mc_conv_weight_grad_workspace_bytes(int numImages, int numImgColors, int numFilters,
+                                           int filterSize, int numModules, int numGroups);
+int mc_conv_weight_grad(const float* images, const float* hidActs, float* weightGrad, int numImages,
+                        int numImgColors, int imgSizeY, int imgSizeX, int numFilters, int filterSize,
+                        int paddingStart, int moduleStride, int numModulesY, int numModulesX,
+                        int numGroups, float scaleTargets, float scaleOutput, void* workspace,
+                        size_t workspaceBytes, mcStream_t stream);
+
 /* A partialSum the library considers a good split of the module axis for this shape on this
  * device (divides numModules; the reference takes it from the layer-def file instead). */
 int mc_conv_weight_acts_pick_partial_sum(int numImages, int numImgColors, int numFilters,

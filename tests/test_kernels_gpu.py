@@ -431,3 +431,28 @@ def test_max_undo_relu_grad_equals_undo_then_relu_gradient():
         assert np.array_equal(host(got), host(ref))
         e = G.max_undo(x, host(g), host(y), N, C, S, size, start, stride, outX) * (x > 0)
         assert np.array_equal(host(got), e)
+
+
+@pytest.mark.parametrize("N,C,H,fs,F,pad,stride,groups", [(128, 32, 16, 5, 32, 2, 1, 1), (16, 3, 32, 5, 32, 2, 1, 1), (32, 96, 8, 5, 192, 2, 1, 1),
+                                                         (128, 192, 8, 3, 192, 1, 1, 1), (12, 8, 9, 3, 16, 1, 2, 2), (5, 3, 10, 5, 4, 0, 1, 1)])
+def test_conv_weight_grad_free_chunking(N, C, H, fs, F, pad, stride, groups):
+    """mc_conv_weight_grad = convWeightActs + reduction of its chunks (layer.cu:503-523) with module-unaligned chunks;
+    run twice: the result must not depend on timing (deterministic chunking)."""
+    m = mc()
+    rng = np.random.default_rng(43)
+    M = _modules(H, fs, pad, stride)
+    img = rng.standard_normal((C * H * H, N)).astype(np.float32)
+    hid = rng.standard_normal((F * M * M, N)).astype(np.float32)
+    geo = (N, C, H, H, F, fs, -pad, stride, M, M, groups)
+    expw = G.weight_acts(img, hid, *geo, partial_sum=0)
+    wsb = m.lib().mc_conv_weight_grad_workspace_bytes(N, C, F, fs, M * M, groups)
+    ws = nans(max(1, wsb // 4))
+    prev = rng.standard_normal(expw.shape).astype(np.float32)
+    dimg, dhid = dev(img), dev(hid)
+    outs = []
+    for _ in range(2):
+        dw = dev(prev)
+        m.call("mc_conv_weight_grad", ptr(dimg), ptr(dhid), ptr(dw), *geo, 0.5, 0.01, ptr(ws), wsb, None)
+        outs.append(host(dw))
+    assert relerr(outs[0], 0.5 * prev + 0.01 * expw) < TOL
+    assert np.array_equal(outs[0], outs[1])
