@@ -31,9 +31,10 @@ int num_cus() {
 
 // implemented in igemm.hip
 int conv_filter_acts_impl(const float*, const float*, float*, const float*, int, int, int, int, int, int, int, int, int, int,
-                          int, int, int, float, float, hipStream_t);
+                          int, int, int, float, float, float*, int, hipStream_t);
 int conv_img_acts_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int, int, int, float,
-                       float, hipStream_t);
+                       float, float*, int, hipStream_t);
+int conv_split_plan(int, long, int, int, int*);
 int conv_weight_acts_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int, int, int, int,
                           float, float, hipStream_t);
 int conv_weight_grad_plan(int, int, int, int, int, int, int*);
@@ -109,10 +110,60 @@ __global__ void __launch_bounds__(256) k_splitk_reduce_tall(const float4* __rest
     }
 }
 
+// float4 form of k_splitk_reduce for a few slabs (n % 4 == 0, ldc % 4 == 0, 16-byte aligned pointers)
+__global__ void k_splitk_reduce4(const float4* __restrict__ slabs, float* C, int m, int n4, int ldc, int chunks, float alpha, float beta,
+                                 const float* __restrict__ bias, int act) {
+    const size_t total4 = (size_t)m * n4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (size_t)gridDim.x * blockDim.x) {
+        float4 acc = slabs[e];
+        for (int q = 1; q < chunks; ++q) {
+            const float4 x = slabs[(size_t)q * total4 + e];
+            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        }
+        const int i = (int)(e / n4), j4 = (int)(e - (size_t)i * n4);
+        float4* dst = reinterpret_cast<float4*>(C + (size_t)i * ldc) + j4;
+        float4 v = make_float4(alpha * acc.x, alpha * acc.y, alpha * acc.z, alpha * acc.w);
+        if (beta != 0.f) {
+            const float4 o = *dst;
+            v.x += beta * o.x; v.y += beta * o.y; v.z += beta * o.z; v.w += beta * o.w;
+        }
+        if (bias) { const float b = bias[i]; v.x += b; v.y += b; v.z += b; v.w += b; }
+        if (act == MC_NEURON_RELU) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }
+        *dst = v;
+    }
+}
+
+// Library-owned scratch for the split-K slabs of the conv forward / backward-data entry points, whose signatures (the
+// reference's host wrappers) carry no workspace: one grow-only buffer per host thread and device, allocated on first
+// need.  Calls that share it must be ordered on one stream (the runtime's compute stream is).
+float* split_scratch(size_t bytes) {
+    struct Buf { float* p = nullptr; size_t cap = 0; int dev = -1; };
+    static thread_local Buf b;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (b.dev != dev || b.cap < bytes) {
+        if (b.p && b.dev == dev) { (void)hipDeviceSynchronize(); (void)hipFree(b.p); }
+        b.p = nullptr; b.cap = 0; b.dev = dev;
+        if (hipMalloc(reinterpret_cast<void**>(&b.p), bytes) != hipSuccess) { b.p = nullptr; return nullptr; }
+        b.cap = bytes;
+    }
+    return b.p;
+}
+
 inline int grid_items(size_t items) {
     const size_t want = (items + TPB - 1) / TPB;
     const size_t cap = (size_t)num_cus() * 16;
     return (int)(want < 1 ? 1 : (want > cap ? cap : want));
+}
+
+int reduce_slabs(const float* slabs, float* C, int m, long n, int chunks, float alpha, float beta, const float* bias, int act, hipStream_t st) {
+    if (n % 4 == 0 && aligned16(C) && aligned16(slabs))
+        hipLaunchKernelGGL(k_splitk_reduce4, dim3(grid_items((size_t)m * (n / 4))), dim3(TPB), 0, st, reinterpret_cast<const float4*>(slabs), C, m,
+                           (int)(n / 4), (int)n, chunks, alpha, beta, bias, act);
+    else
+        hipLaunchKernelGGL(k_splitk_reduce, dim3(grid_items((size_t)m * n)), dim3(TPB), 0, st, slabs, C, m, (int)n, (int)n, chunks, alpha, beta, bias,
+                           act, (const float*)nullptr, 0);
+    return launch_status("conv split-K reduce");
 }
 
 int pick_gemm_chunks(int m, int n, int k) {
@@ -158,10 +209,9 @@ int mc_conv_filter_acts(const float* images, const float* filters, float* target
                         int imgSizeY, int imgSizeX, int numFilters, int filterSize, int paddingStart, int moduleStride,
                         int numModulesY, int numModulesX, int numGroups, float scaleTargets, float scaleOutput,
                         mcStream_t s) {
-    MC_REQUIRE(images && filters && targets, "mc_conv_filter_acts: null pointer");
-    return conv_filter_acts_impl(images, filters, targets, nullptr, MC_NEURON_NONE, numImages, numImgColors, imgSizeY,
-                                 imgSizeX, numFilters, filterSize, paddingStart, moduleStride, numModulesY, numModulesX,
-                                 numGroups, 0, scaleTargets, scaleOutput, S(s));
+    return mc_conv_filter_acts_fused(images, filters, targets, nullptr, MC_NEURON_NONE, numImages, numImgColors, imgSizeY, imgSizeX,
+                                     numFilters, filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups,
+                                     scaleTargets, scaleOutput, s);
 }
 
 int mc_conv_filter_acts_fused(const float* images, const float* filters, float* targets, const float* biases, int neuron,
@@ -170,18 +220,46 @@ int mc_conv_filter_acts_fused(const float* images, const float* filters, float* 
                               float scaleTargets, float scaleOutput, mcStream_t s) {
     MC_REQUIRE(images && filters && targets, "mc_conv_filter_acts_fused: null pointer");
     MC_REQUIRE(neuron == MC_NEURON_NONE || neuron == MC_NEURON_RELU, "mc_conv_filter_acts_fused: unknown neuron %d", neuron);
+    // few columns (modules x images): split K so the grid fills the device, reduce the slabs with the epilogue
+    if (numImages > 0 && numImgColors > 0 && numFilters > 0 && numGroups > 0 && filterSize > 0 && numModulesY > 0 && numModulesX > 0 &&
+        numFilters % numGroups == 0 && numImgColors % numGroups == 0) {
+        const long cols = (long)numModulesY * numModulesX * numImages;
+        int kc = 0;
+        const int chunks = conv_split_plan(numFilters / numGroups, cols, numImgColors / numGroups * filterSize * filterSize, numGroups, &kc);
+        float* slabs = chunks > 1 ? split_scratch((size_t)chunks * numFilters * cols * sizeof(float)) : nullptr;
+        if (slabs) {
+            int rc = conv_filter_acts_impl(images, filters, targets, nullptr, MC_NEURON_NONE, numImages, numImgColors, imgSizeY, imgSizeX,
+                                           numFilters, filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 0,
+                                           0.f, 1.f, slabs, kc, S(s));
+            if (rc) return rc;
+            return reduce_slabs(slabs, targets, numFilters, cols, chunks, scaleOutput, scaleTargets, biases, neuron, S(s));
+        }
+    }
     return conv_filter_acts_impl(images, filters, targets, biases, neuron, numImages, numImgColors, imgSizeY, imgSizeX,
                                  numFilters, filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 0,
-                                 scaleTargets, scaleOutput, S(s));
+                                 scaleTargets, scaleOutput, nullptr, 0, S(s));
 }
 
 int mc_conv_img_acts(const float* hidActs, const float* filters, float* targets, int numImages, int numImgColors,
                      int imgSizeY, int imgSizeX, int numFilters, int filterSize, int paddingStart, int moduleStride,
                      int numModulesY, int numModulesX, int numGroups, float scaleTargets, float scaleOutput, mcStream_t s) {
     MC_REQUIRE(hidActs && filters && targets, "mc_conv_img_acts: null pointer");
+    if (numImages > 0 && numImgColors > 0 && numFilters > 0 && numGroups > 0 && filterSize > 0 && imgSizeY > 0 && imgSizeX > 0 &&
+        numFilters % numGroups == 0 && numImgColors % numGroups == 0) {
+        const long cols = (long)imgSizeY * imgSizeX * numImages;
+        int kc = 0;
+        const int chunks = conv_split_plan(numImgColors / numGroups, cols, filterSize * filterSize * (numFilters / numGroups), numGroups, &kc);
+        float* slabs = chunks > 1 ? split_scratch((size_t)chunks * numImgColors * cols * sizeof(float)) : nullptr;
+        if (slabs) {
+            int rc = conv_img_acts_impl(hidActs, filters, targets, numImages, numImgColors, imgSizeY, imgSizeX, numFilters, filterSize,
+                                        paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 0, 0.f, 1.f, slabs, kc, S(s));
+            if (rc) return rc;
+            return reduce_slabs(slabs, targets, numImgColors, cols, chunks, scaleOutput, scaleTargets, nullptr, MC_NEURON_NONE, S(s));
+        }
+    }
     return conv_img_acts_impl(hidActs, filters, targets, numImages, numImgColors, imgSizeY, imgSizeX, numFilters, filterSize,
                               paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 0, scaleTargets, scaleOutput,
-                              S(s));
+                              nullptr, 0, S(s));
 }
 
 int mc_conv_weight_acts(const float* images, const float* hidActs, float* targets, int numImages, int numImgColors,
@@ -229,7 +307,7 @@ int mc_local_filter_acts(const float* images, const float* filters, float* targe
     MC_REQUIRE(images && filters && targets, "mc_local_filter_acts: null pointer");
     return conv_filter_acts_impl(images, filters, targets, nullptr, MC_NEURON_NONE, numImages, numImgColors, imgSizeY, imgSizeX,
                                  numFilters, filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 1,
-                                 scaleTargets, scaleOutput, S(s));
+                                 scaleTargets, scaleOutput, nullptr, 0, S(s));
 }
 
 int mc_local_img_acts(const float* hidActs, const float* filters, float* targets, int numImages, int numImgColors,
@@ -238,7 +316,7 @@ int mc_local_img_acts(const float* hidActs, const float* filters, float* targets
     MC_REQUIRE(hidActs && filters && targets, "mc_local_img_acts: null pointer");
     return conv_img_acts_impl(hidActs, filters, targets, numImages, numImgColors, imgSizeY, imgSizeX, numFilters, filterSize,
                               paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 1, scaleTargets, scaleOutput,
-                              S(s));
+                              nullptr, 0, S(s));
 }
 
 size_t mc_gemm_workspace_bytes(int m, int n, int k) {

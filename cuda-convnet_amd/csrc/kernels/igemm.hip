@@ -821,19 +821,25 @@ int make_convg(ConvG& cg, int N, int C, int H, int W, int F, int fs, int pad, in
 // =================================================================================
 int conv_filter_acts_impl(const float* images, const float* filters, float* targets, const float* biases, int neuron,
                           int N, int C, int H, int W, int F, int fs, int pad, int stride, int MY, int MX, int groups,
-                          int local, float scaleTargets, float scaleOutput, hipStream_t st) {
+                          int local, float scaleTargets, float scaleOutput, float* slabs, int kChunk, hipStream_t st) {
     ConvG cg;
     int rc = make_convg(cg, N, C, H, W, F, fs, pad, stride, MY, MX, groups, local, local ? "localFilterActs" : "convFilterActs");
     if (rc) return rc;
+    int chunks = 1;
     // shared filters: one product over all M*N columns.  Unshared (filter_acts.cu conv=false): M products in one
     // launch, batch = module, each over its own N columns with its own filter bank W[m].
     Dims d{cg.fpg, local ? N : cg.M * N, cg.fc * cg.fp, cg.fc * cg.fp, groups, 0, local ? cg.M : 1, local ? N : 0};
     Epi ep{targets, cg.M * N, cg.fpg, 0, 0, scaleOutput, scaleTargets, biases, neuron, nullptr, 0};
+    if (slabs && kChunk > 0 && !local) {   // split K: every chunk writes a plain slab, the caller reduces and applies the epilogue
+        d.kChunk = kChunk;
+        chunks = ceil_div(d.Kg, kChunk);
+        ep = Epi{slabs, cg.M * N, cg.fpg, 0, (long)F * cg.M * N, 1.f, 0.f, nullptr, MC_NEURON_NONE, nullptr, 0};
+    }
     MatP pa{filters, F, cg.fpg, cg.fpg, (unsigned)((size_t)(local ? cg.M : 1) * cg.fc * cg.fp * F * 4), local ? cg.fc * cg.fp * F : 0};  // filters[k*F + g*fpg + f]
     ConvP pb{images, cg.M * N, (unsigned)((size_t)C * H * W * N * 4)};
     const bool vec = (N % 4 == 0) && (cg.fpg % 4 == 0) && (F % 4 == 0) && aligned16(images) && aligned16(filters);
-    if (vec) return launch_rows_cols<MatNatAddr, PatchNatAddr, MC_BK, 4>(pa, pb, cg, d, ep, 1, st);
-    return launch_rows_cols<MatNatAddr, PatchNatAddr, MC_BK, 1>(pa, pb, cg, d, ep, 1, st);
+    if (vec) return launch_rows_cols<MatNatAddr, PatchNatAddr, MC_BK, 4>(pa, pb, cg, d, ep, chunks, st);
+    return launch_rows_cols<MatNatAddr, PatchNatAddr, MC_BK, 1>(pa, pb, cg, d, ep, chunks, st);
 }
 
 // =================================================================================
@@ -841,14 +847,20 @@ int conv_filter_acts_impl(const float* images, const float* filters, float* targ
 // =================================================================================
 int conv_img_acts_impl(const float* hidActs, const float* filters, float* targets, int N, int C, int H, int W, int F,
                        int fs, int pad, int stride, int MY, int MX, int groups, int local, float scaleTargets,
-                       float scaleOutput, hipStream_t st) {
+                       float scaleOutput, float* slabs, int kChunk, hipStream_t st) {
     ConvG cg;
     int rc = make_convg(cg, N, C, H, W, F, fs, pad, stride, MY, MX, groups, local, local ? "localImgActs" : "convImgActs");
     if (rc) return rc;
+    int chunks = 1;
     // unshared (img_acts.cu conv=false): one product per image pixel (batch = pixel), whose A operand gathers, tap
     // by tap, the filter bank of the module that sees the pixel at that tap (FiltTAddr)
     Dims d{cg.fc, local ? N : H * W * N, cg.fp * cg.fpg, cg.fp * cg.fpg, groups, 0, local ? H * W : 1, local ? N : 0};
     Epi ep{targets, H * W * N, cg.fc, 0, 0, scaleOutput, scaleTargets, nullptr, MC_NEURON_NONE, nullptr, 0};
+    if (slabs && kChunk > 0 && !local) {
+        d.kChunk = kChunk;
+        chunks = ceil_div(d.Kg, kChunk);
+        ep = Epi{slabs, H * W * N, cg.fc, 0, (long)C * H * W * N, 1.f, 0.f, nullptr, MC_NEURON_NONE, nullptr, 0};
+    }
     ConvP pa{filters, cg.fc, (unsigned)((size_t)(local ? cg.M : 1) * cg.fc * cg.fp * F * 4)};
     ConvP pb{hidActs, H * W * N, (unsigned)((size_t)F * cg.M * N * 4)};
     // group offset of the A operand rows: channel c of group g uses filter rows (cl*fp+p), columns g*fpg+fl
@@ -856,11 +868,11 @@ int conv_img_acts_impl(const float* hidActs, const float* filters, float* target
     if (stride == 1 && groups == 1 && !local) {
         // with one group the transposed-filter operand is a plain k-contiguous matrix: row c, k = p*F + f at c*fp*F + k
         MatP pm{filters, cg.fp * F, cg.fc, 0, pa.bytes, 0};
-        if (vec) return launch_rows_cols<MatKcAddr, HidNatS1Addr, MC_BK, 4>(pm, pb, cg, d, ep, 1, st);
-        return launch_rows_cols<MatKcAddr, HidNatS1Addr, MC_BK, 1>(pm, pb, cg, d, ep, 1, st);
+        if (vec) return launch_rows_cols<MatKcAddr, HidNatS1Addr, MC_BK, 4>(pm, pb, cg, d, ep, chunks, st);
+        return launch_rows_cols<MatKcAddr, HidNatS1Addr, MC_BK, 1>(pm, pb, cg, d, ep, chunks, st);
     }
-    if (vec) return launch_rows_cols<FiltTAddr, HidNatAddr, MC_BK, 4>(pa, pb, cg, d, ep, 1, st);
-    return launch_rows_cols<FiltTAddr, HidNatAddr, MC_BK, 1>(pa, pb, cg, d, ep, 1, st);
+    if (vec) return launch_rows_cols<FiltTAddr, HidNatAddr, MC_BK, 4>(pa, pb, cg, d, ep, chunks, st);
+    return launch_rows_cols<FiltTAddr, HidNatAddr, MC_BK, 1>(pa, pb, cg, d, ep, chunks, st);
 }
 
 // =================================================================================
@@ -890,6 +902,23 @@ int conv_weight_acts_impl(const float* images, const float* hidActs, float* targ
     const bool vec = (N % 4 == 0) && aligned16(images) && aligned16(hidActs);
     if (vec) return launch_rows_cols<PatchKcAddr, MatKcAddr, MC_BK_KC, 4>(pa, pb, cg, d, ep, chunks, st);
     return launch_rows_cols<PatchKcAddr, MatKcAddr, MC_BK_KC, 1>(pa, pb, cg, d, ep, chunks, st);
+}
+
+// K split for the forward / backward-data products of layers with few columns (NIN conv3: 64 modules x 128 images):
+// with 96x128 tiles the grid would cover half the device, so K is cut into as many chunks as bring it to about one
+// workgroup per CU (at most 8, each >= 512 long, a multiple of 32); slabs + a fixed-order reduction as for the
+// weight gradients.  A pure function of the shape and the CU count.  Returns the chunk count (1 = no split).
+int conv_split_plan(int rows, long cols, int K, int groups, int* kChunkOut) {
+    const long tiles = (long)ceil_div(rows, 96) * ceil_div(cols, 128) * groups;
+    long chunks = num_cus() / tiles;
+    *kChunkOut = 0;
+    if (chunks < 2 || K < 1024) return 1;
+    if (chunks > 8) chunks = 8;
+    long kc = (ceil_div(K, chunks) + 31) / 32 * 32;
+    if (kc < 512) kc = 512;
+    if (kc >= K) return 1;
+    *kChunkOut = (int)kc;
+    return ceil_div(K, kc);
 }
 
 // Chunking of the (module, image) axis for mc_conv_weight_grad: as many chunks as keep about one workgroup per CU
