@@ -461,6 +461,9 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
 #pragma unroll
         for (int u = 0; u < NS; ++u)
             if (u < nk) fetch(as[u], bs[u], u);
+        // per-row bias of this tile -> LDS (behind the three stages), so the epilogue does not wait on one global load
+        // per output row; visible to the consumers through the first barrier
+        if (ep.bias && tid < BM) smem[3 * STAGE + tid] = (i0 + tid < d.Mg) ? ep.bias[i0 + tid + g * ep.rowG] : 0.f;
         commit(as[0], bs[0], 0);
         if (NS < nk) fetch(as[0], bs[0], NS);
         if (1 < nk) {
@@ -632,7 +635,7 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
                     const long idx = (long)row * ep.ldc + j + g * ep.colG;
                     float v = ep.alpha * acc[a][b][r];
                     if (ep.beta != 0.f) v += ep.beta * C[idx];
-                    if (ep.bias) v += ep.bias[row];
+                    if (ep.bias) v += smem[3 * STAGE + (wm * MT + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
                     if (ep.act == MC_NEURON_RELU) v = v < 0.f ? 0.f : v;
                     if (ep.mask && !(ep.mask[(long)row * ep.ldmask + j + g * ep.colG] > 0.f)) v = 0.f;
                     C[idx] = v;
@@ -651,7 +654,7 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     typedef Loader<AADDR, BM, BK, VEC> LA;
     typedef Loader<BADDR, BN, BK, VEC> LB;
-    constexpr size_t lds = 3 * (LA::LDS_FLOATS + LB::LDS_FLOATS) * sizeof(float);
+    constexpr size_t lds = (3 * (LA::LDS_FLOATS + LB::LDS_FLOATS) + BM) * sizeof(float);   // three stages + the tile's bias column
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = mc_igemm<AADDR, BADDR, MT, NT, WM, WN, BK, VEC, NS>;
     Dims d = d0;
