@@ -334,7 +334,7 @@ static int gemm_entry(const char* who, const float* A, const float* B, float* C,
     MC_REQUIRE(neuron == MC_NEURON_NONE || neuron == MC_NEURON_RELU, "%s: unknown neuron %d", who, neuron);
     MC_REQUIRE(!mask || ldmask >= n, "%s: mask leading dimension too small", who);
     MC_REQUIRE((size_t)(transA ? k : m) * lda < (1ull << 30) && (size_t)(transB ? n : k) * ldb < (1ull << 30) &&
-                   (size_t)m * ldc < (1ull << 31),
+                   (size_t)m * ldc < (1ull << 30) && (!mask || (size_t)m * ldmask < (1ull << 30)),
                "%s: operand exceeds the 4 GiB buffer-descriptor range", who);
     int chunks = pick_gemm_chunks(m, n, k);
     if (chunks > 1 && workspace && workspaceBytes >= (size_t)chunks * m * n * sizeof(float) && aligned16(workspace)) {

@@ -91,6 +91,8 @@ struct Epi {
     int act;            // MC_NEURON_*
     const float* mask;  // nullable: outputs whose mask element is not > 0 are written as 0 (relu gradient)
     int ldmask;
+    unsigned cBytes;    // extent of one chunk's output in bytes: range of the store descriptor
+    unsigned mBytes;    // extent of the mask in bytes
 };
 // (batch b of a batched launch writes columns [b * d.colB, b * d.colB + d.Ng) of C)
 
@@ -620,26 +622,33 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     }
 #endif
 
-    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* C = ep.C + q * ep.chunkStride;
+    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // Branch-free like the loads: every element goes through a buffer descriptor over this chunk's output
+    // (ep.cBytes) and an element outside the product is stored at offset 0xFFFFFFFF, which the range check drops.
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(ep.C + q * ep.chunkStride, 0, ep.cBytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ep.mask ? ep.mask : ep.C), 0, ep.mask ? ep.mBytes : 0u, 0x00020000);
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
 #pragma unroll
         for (int b = 0; b < NT; ++b) {
             const int j = j0 + (wn * NT + b) * 32 + l31;
+            const bool jok = j < jlim;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int i = i0 + (wm * MT + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (i < ilim && j < jlim) {
-                    const int row = i + g * ep.rowG;
-                    const long idx = (long)row * ep.ldc + j + g * ep.colG;
-                    float v = ep.alpha * acc[a][b][r];
-                    if (ep.beta != 0.f) v += ep.beta * C[idx];
-                    if (ep.bias) v += smem[3 * STAGE + (wm * MT + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
-                    if (ep.act == MC_NEURON_RELU) v = v < 0.f ? 0.f : v;
-                    if (ep.mask && !(ep.mask[(long)row * ep.ldmask + j + g * ep.colG] > 0.f)) v = 0.f;
-                    C[idx] = v;
+                const int rl = (wm * MT + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int i = i0 + rl;
+                const bool ok = jok & (i < ilim);
+                const int row = i + g * ep.rowG;
+                const unsigned off = ok ? (unsigned)(row * ep.ldc + j + g * ep.colG) * 4u : OOB;
+                float v = ep.alpha * acc[a][b][r];
+                if (ep.beta != 0.f) v += ep.beta * __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rc, off, 0, 0));
+                if (ep.bias) v += smem[3 * STAGE + rl];
+                if (ep.act == MC_NEURON_RELU) v = v < 0.f ? 0.f : v;
+                if (ep.mask) {
+                    const unsigned moff = ok ? (unsigned)(row * ep.ldmask + j + g * ep.colG) * 4u : OOB;
+                    if (!(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, moff, 0, 0)) > 0.f)) v = 0.f;
                 }
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, off, 0, 0);
             }
         }
     }
@@ -832,11 +841,11 @@ int conv_filter_acts_impl(const float* images, const float* filters, float* targ
     // shared filters: one product over all M*N columns.  Unshared (filter_acts.cu conv=false): M products in one
     // launch, batch = module, each over its own N columns with its own filter bank W[m].
     Dims d{cg.fpg, local ? N : cg.M * N, cg.fc * cg.fp, cg.fc * cg.fp, groups, 0, local ? cg.M : 1, local ? N : 0};
-    Epi ep{targets, cg.M * N, cg.fpg, 0, 0, scaleOutput, scaleTargets, biases, neuron, nullptr, 0};
+    Epi ep{targets, cg.M * N, cg.fpg, 0, 0, scaleOutput, scaleTargets, biases, neuron, nullptr, 0, (unsigned)((size_t)F * cg.M * N * 4), 0};
     if (slabs && kChunk > 0 && !local) {   // split K: every chunk writes a plain slab, the caller reduces and applies the epilogue
         d.kChunk = kChunk;
         chunks = ceil_div(d.Kg, kChunk);
-        ep = Epi{slabs, cg.M * N, cg.fpg, 0, (long)F * cg.M * N, 1.f, 0.f, nullptr, MC_NEURON_NONE, nullptr, 0};
+        ep = Epi{slabs, cg.M * N, cg.fpg, 0, (long)F * cg.M * N, 1.f, 0.f, nullptr, MC_NEURON_NONE, nullptr, 0, (unsigned)((size_t)F * cg.M * N * 4), 0};
     }
     MatP pa{filters, F, cg.fpg, cg.fpg, (unsigned)((size_t)(local ? cg.M : 1) * cg.fc * cg.fp * F * 4), local ? cg.fc * cg.fp * F : 0};  // filters[k*F + g*fpg + f]
     ConvP pb{images, cg.M * N, (unsigned)((size_t)C * H * W * N * 4)};
@@ -858,11 +867,11 @@ int conv_img_acts_impl(const float* hidActs, const float* filters, float* target
     // unshared (img_acts.cu conv=false): one product per image pixel (batch = pixel), whose A operand gathers, tap
     // by tap, the filter bank of the module that sees the pixel at that tap (FiltTAddr)
     Dims d{cg.fc, local ? N : H * W * N, cg.fp * cg.fpg, cg.fp * cg.fpg, groups, 0, local ? H * W : 1, local ? N : 0};
-    Epi ep{targets, H * W * N, cg.fc, 0, 0, scaleOutput, scaleTargets, nullptr, MC_NEURON_NONE, nullptr, 0};
+    Epi ep{targets, H * W * N, cg.fc, 0, 0, scaleOutput, scaleTargets, nullptr, MC_NEURON_NONE, nullptr, 0, (unsigned)((size_t)C * H * W * N * 4), 0};
     if (slabs && kChunk > 0 && !local) {
         d.kChunk = kChunk;
         chunks = ceil_div(d.Kg, kChunk);
-        ep = Epi{slabs, H * W * N, cg.fc, 0, (long)C * H * W * N, 1.f, 0.f, nullptr, MC_NEURON_NONE, nullptr, 0};
+        ep = Epi{slabs, H * W * N, cg.fc, 0, (long)C * H * W * N, 1.f, 0.f, nullptr, MC_NEURON_NONE, nullptr, 0, (unsigned)((size_t)C * H * W * N * 4), 0};
     }
     ConvP pa{filters, cg.fc, (unsigned)((size_t)(local ? cg.M : 1) * cg.fc * cg.fp * F * 4)};
     ConvP pb{hidActs, H * W * N, (unsigned)((size_t)F * cg.M * N * 4)};
@@ -899,7 +908,7 @@ int conv_weight_acts_impl(const float* images, const float* hidActs, float* targ
         kChunk = partialSum * N;
     }
     Dims d{cg.fc * cg.fp, cg.fpg, cg.M * N, kChunk, groups, 0, 1, 0};
-    Epi ep{targets, F, 0, cg.fpg, (long)cg.fc * cg.fp * F, scaleOutput, scaleTargets, nullptr, MC_NEURON_NONE, nullptr, 0};
+    Epi ep{targets, F, 0, cg.fpg, (long)cg.fc * cg.fp * F, scaleOutput, scaleTargets, nullptr, MC_NEURON_NONE, nullptr, 0, (unsigned)((size_t)cg.fc * cg.fp * F * 4), 0};
     ConvP pa{images, cg.fc * cg.fp, (unsigned)((size_t)C * H * W * N * 4)};
     MatP pb{hidActs, cg.M * N, cg.fpg, cg.fpg * cg.M * N, (unsigned)((size_t)F * cg.M * N * 4), 0};  // hid[(g*fpg+f)*M*N + k]
     const bool vec = (N % 4 == 0) && aligned16(images) && aligned16(hidActs);
@@ -959,7 +968,8 @@ int gemm_impl(const float* A, const float* B, float* Cm, int m, int n, int k, in
         chunks = ceil_div(k, kChunk);
     }
     Dims d{m, n, k, kChunk, 1, 0, 1, 0};
-    Epi ep{Cm, ldc, 0, 0, chunkStride, alpha, beta, rowBias, neuron, mask, ldmask};
+    Epi ep{Cm, ldc, 0, 0, chunkStride, alpha, beta, rowBias, neuron, mask, ldmask, (unsigned)(((size_t)(m - 1) * ldc + n) * 4),
+           mask ? (unsigned)(((size_t)(m - 1) * ldmask + n) * 4) : 0u};
     // operand extents in bytes: (rows - 1) * ld + row length
     const size_t ea = transA ? (size_t)(k - 1) * lda + m : (size_t)(m - 1) * lda + k;
     const size_t eb = transB ? (size_t)(n - 1) * ldb + k : (size_t)(k - 1) * ldb + n;
