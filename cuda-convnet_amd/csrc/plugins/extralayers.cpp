@@ -50,9 +50,7 @@ protected:
     void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE) override {
         const int N = numCases(), P = pixels(_prev[inpIdx]->getNumOutputs()), cols = P * N;
         const size_t wsb = mc_gemm_workspace_bytes(_in, cols, _out);
-        // opt-in: measured slower than the separate relu-gradient pass on the short-K cccp products (see FCLayer::bpropActs)
-        static const bool fuse = getenv("MC_FUSE_RELU_GRAD_GEMM") != nullptr;
-        const float* mask = (fuse && scaleTargets == 0.f) ? claimReluGradMask(inpIdx) : nullptr;
+        const float* mask = scaleTargets == 0.f ? claimReluGradMask(inpIdx) : nullptr;   // see FCLayer::bpropActs
         for (int ch = 0; ch < _channels; ch++) {
             const float* W = _weights[inpIdx].getW() + (size_t)ch * _out * _in;
             const float* G = v.data() + (size_t)ch * _out * cols;
