@@ -76,7 +76,8 @@ struct Dims {
     int Mg, Ng, Kg;   // GEMM extents (per group)
     int kChunk;       // k extent of one chunk (multiple of 4 when a KC loader is vectorised)
     int groups;
-    int xcdSwizzle;   // set by launch_cfg when gridDim.x % 8 == 0
+    int xcdSwizzle;   // set by launch_cfg when column tiles and column workers are both multiples of 8
+    int colTiles;     // column tiles of the product (set by launch_cfg); gridDim.x = column workers <= colTiles
     int batches;      // independent products sharing one launch (unshared layers: one per module / pixel); >= 1
     int colB;         // column offset of batch b in the B operand and in C: b * colB
 };
@@ -422,19 +423,25 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     // while the producers fill stage (t+2) % 3.
     constexpr int STAGE = LA::LDS_FLOATS + LB::LDS_FLOATS;
 
-    // column-tile index: with d.xcdSwizzle the grid's x extent is a multiple of 8 and workgroups are dealt
-    // round-robin over the 8 XCDs, so workgroup b -> tile (b % 8) * (gridDim.x / 8) + b / 8 keeps
-    // neighbouring column tiles (neighbouring modules, overlapping patches) on one XCD's L2.
-    const int bx = d.xcdSwizzle ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    // Column tiles.  A workgroup is a "column worker": worker w = blockIdx.x of gridDim.x takes column tiles
+    // w, w + gridDim.x, ... and runs their K loops back to back as ONE pipeline of nTiles * nk steps, so only the
+    // first tile pays the pipeline fill (short-K products: K = 75 ... 192 is 5-12 steps per tile).  With
+    // gridDim.x == d.colTiles every worker has one tile.  XCD awareness: with d.xcdSwizzle (column tiles and
+    // workers both multiples of 8; workgroups are dealt round-robin over the 8 XCDs) logical tile t maps to
+    // column block (t % 8) * (colTiles / 8) + t / 8, which keeps neighbouring column blocks (neighbouring
+    // modules, overlapping patches) on one XCD's L2; a worker's tiles all share t % 8.
+    auto col_block = [&](int t) { return d.xcdSwizzle ? (t & 7) * (d.colTiles >> 3) + (t >> 3) : t; };
+    const int nTiles = (d.colTiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // >= 1
     // blockIdx.z = (k-chunk q, group g, batch b)
     const int zb = blockIdx.z / d.batches, b = blockIdx.z - zb * d.batches;
     const int q = zb / d.groups, g = zb - q * d.groups;
     const int coff = b * d.colB;                      // first B / C column of this batch
-    const int i0 = blockIdx.y * BM, j0 = coff + bx * BN;
+    const int i0 = blockIdx.y * BM;
     const int ilim = d.Mg, jlim = coff + d.Ng;
     const int kbeg = q * d.kChunk;
     const int kend = min(kbeg + d.kChunk, d.Kg);
-    const int nk = (kend - kbeg + BK - 1) / BK;   // >= 1 K steps; barriers executed by every wave: 1 + nk
+    const int nkTile = (kend - kbeg + BK - 1) / BK;   // K steps per tile, >= 1
+    const int nk = nkTile * nTiles;                   // pipeline steps; barriers executed by every wave: 1 + nk
 
     if (threadIdx.x >= THREADS) {
         // ------------------------------ producer waves ------------------------------
@@ -452,9 +459,17 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         const __amdgpu_buffer_rsrc_t ra = make_rsrc(AADDR::base(pa), pa.bytes), rb = make_rsrc(BADDR::base(pb), pb.bytes);
         LA as[NS];
         LB bs[NS];
-        auto fetch = [&](auto& la, auto& lb, int u) {
-            la.fetch(ra, pa, cg, g, b, kbeg + u * BK, kend, i0, ilim, tid);
-            lb.fetch(rb, pb, cg, g, b, kbeg + u * BK, kend, j0, jlim, tid);
+        // fetches are issued in step order (u = 0, 1, 2, ...), so the (tile, K position) of the next one is a
+        // running pair of workgroup-uniform counters rather than a division of u
+        int fk = 0, fj0 = coff + col_block(blockIdx.x) * BN, ft = blockIdx.x;
+        auto fetch = [&](auto& la, auto& lb, int) {
+            la.fetch(ra, pa, cg, g, b, kbeg + fk * BK, kend, i0, ilim, tid);
+            lb.fetch(rb, pb, cg, g, b, kbeg + fk * BK, kend, fj0, jlim, tid);
+            if (++fk == nkTile) {
+                fk = 0;
+                ft += gridDim.x;
+                fj0 = coff + col_block(ft) * BN;
+            }
         };
         auto commit = [&](const auto& la, const auto& lb, int stage) {
             la.commit(smem + stage * STAGE, tid);
@@ -529,12 +544,6 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     const int wm = wave / WN, wn = wave % WN;
 
     f32x16 acc[MT][NT];
-#pragma unroll
-    for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     // LDS -> register fragments, software-pipelined ACROSS K steps: "slab" s holds the operands of one
     // MFMA k-step (2 k values: lane half h supplies k = kof(s) + h-dependent offset).  The reads of slab
@@ -573,6 +582,43 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         }
     };
 
+    // Tile store: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // Branch-free like the loads: every element goes through a buffer descriptor over this chunk's output
+    // (ep.cBytes) and an element outside the product is stored at offset 0xFFFFFFFF, which the range check drops.
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(ep.C + q * ep.chunkStride, 0, ep.cBytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ep.mask ? ep.mask : ep.C), 0, ep.mask ? ep.mBytes : 0u, 0x00020000);
+    auto store_tile = [&](int j0) {
+        // the row terms below do not change from tile to tile; an opaque copy of h keeps the compiler from
+        // hoisting ~64 registers per 32-row block of them out of the tile loop (measured: spills in the 160-row tiles)
+        int hh = h;
+        asm volatile("" : "+v"(hh));
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int j = j0 + (wn * NT + b) * 32 + l31;
+                const bool jok = j < jlim;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = (wm * MT + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const int i = i0 + rl;
+                    const bool ok = jok & (i < ilim);
+                    const int row = i + g * ep.rowG;
+                    const unsigned off = ok ? (unsigned)(row * ep.ldc + j + g * ep.colG) * 4u : OOB;
+                    float v = ep.alpha * acc[a][b][r];
+                    if (ep.beta != 0.f) v += ep.beta * __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rc, off, 0, 0));
+                    if (ep.bias) v += smem[3 * STAGE + rl];
+                    if (ep.act == MC_NEURON_RELU) v = v < 0.f ? 0.f : v;
+                    if (ep.mask) {
+                        const unsigned moff = ok ? (unsigned)(row * ep.ldmask + j + g * ep.colG) * 4u : OOB;
+                        if (!(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, moff, 0, 0)) > 0.f)) v = 0.f;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, off, 0, 0);
+                }
+            }
+        }
+    };
+
     lds_done_barrier();   // tiles 0 and 1 visible
 #pragma unroll
     for (int s_ = 0; s_ < PF; ++s_) load_slab(smem, smem + LA::LDS_FLOATS, s_);
@@ -583,7 +629,16 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
 #ifdef MC_STAMP
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    for (int t = 0; t < nk; ++t) {
+    // one trip per column tile of this worker; the accumulators are (re)defined at the top of the trip, so no
+    // accumulator value is live around the outer loop
+    for (int ct = blockIdx.x; ct < d.colTiles; ct += gridDim.x) {
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    for (int t = 0; t < nkTile; ++t) {
         const int nstage = stage == 2 ? 0 : stage + 1;
         STAMP(c0);
         const float* cA = smem + stage * STAGE;
@@ -614,6 +669,9 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
 #endif
         stage = nstage;
     }
+    // this tile's K loop is complete: store it while the producers run ahead into the next tile
+    store_tile(coff + col_block(ct) * BN);
+    }
 #ifdef MC_STAMP
     if (tid == 0) {
         const int blk = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -622,36 +680,6 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     }
 #endif
 
-    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    // Branch-free like the loads: every element goes through a buffer descriptor over this chunk's output
-    // (ep.cBytes) and an element outside the product is stored at offset 0xFFFFFFFF, which the range check drops.
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(ep.C + q * ep.chunkStride, 0, ep.cBytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ep.mask ? ep.mask : ep.C), 0, ep.mask ? ep.mBytes : 0u, 0x00020000);
-#pragma unroll
-    for (int a = 0; a < MT; ++a) {
-#pragma unroll
-        for (int b = 0; b < NT; ++b) {
-            const int j = j0 + (wn * NT + b) * 32 + l31;
-            const bool jok = j < jlim;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = (wm * MT + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int i = i0 + rl;
-                const bool ok = jok & (i < ilim);
-                const int row = i + g * ep.rowG;
-                const unsigned off = ok ? (unsigned)(row * ep.ldc + j + g * ep.colG) * 4u : OOB;
-                float v = ep.alpha * acc[a][b][r];
-                if (ep.beta != 0.f) v += ep.beta * __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rc, off, 0, 0));
-                if (ep.bias) v += smem[3 * STAGE + rl];
-                if (ep.act == MC_NEURON_RELU) v = v < 0.f ? 0.f : v;
-                if (ep.mask) {
-                    const unsigned moff = ok ? (unsigned)(row * ep.ldmask + j + g * ep.colG) * 4u : OOB;
-                    if (!(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, moff, 0, 0)) > 0.f)) v = 0.f;
-                }
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, off, 0, 0);
-            }
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -673,12 +701,23 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
         attr_done = true;
     }
     dim3 grid(ceil_div(d.Ng, BN), ceil_div(d.Mg, BM), chunks * d.groups * d.batches);
-    static const bool noswz = getenv("MC_IGEMM_NOSWZ") != nullptr;
-    d.xcdSwizzle = (grid.x % 8 == 0 && grid.x >= 16 && !noswz) ? 1 : 0;
-    if (grid.y > 65535 || grid.z > 65535) {
-        set_error("igemm: grid too large (%u,%u,%u)", grid.x, grid.y, grid.z);
-        return MC_EINVAL;
+    d.colTiles = (int)grid.x;
+    // Short K loops (a handful of steps per tile): fewer workgroups than tiles, as many as are resident at once, each
+    // running its tiles as one pipeline (see the kernel) instead of paying the pipeline fill per tile.
+    const int stepsPerTile = ceil_div(d.kChunk < d.Kg ? d.kChunk : d.Kg, BK);
+    static const bool nopersist = getenv("MC_IGEMM_NOPERSIST") != nullptr;
+    if (!nopersist && stepsPerTile <= 24 && (long)grid.x * grid.y * grid.z > 2L * num_cus()) {
+        static int perCU = 0;
+        if (perCU == 0) {
+            int nb = 0;
+            perCU = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 2 * THREADS, lds) == hipSuccess && nb > 0) ? nb : 1;
+        }
+        long workers = (long)perCU * num_cus() / ((long)grid.y * grid.z);
+        if (workers >= 8) workers = workers / 8 * 8;
+        if (workers >= 1 && workers < (long)grid.x) grid.x = (unsigned)workers;
     }
+    static const bool noswz = getenv("MC_IGEMM_NOSWZ") != nullptr;
+    d.xcdSwizzle = (d.colTiles % 8 == 0 && grid.x % 8 == 0 && d.colTiles >= 16 && !noswz) ? 1 : 0;
     hipLaunchKernelGGL(kern, grid, dim3(2 * THREADS), lds, st, pa, pb, cg, d, ep);
     return launch_status("mc_igemm");
 }
@@ -840,7 +879,7 @@ int conv_filter_acts_impl(const float* images, const float* filters, float* targ
     int chunks = 1;
     // shared filters: one product over all M*N columns.  Unshared (filter_acts.cu conv=false): M products in one
     // launch, batch = module, each over its own N columns with its own filter bank W[m].
-    Dims d{cg.fpg, local ? N : cg.M * N, cg.fc * cg.fp, cg.fc * cg.fp, groups, 0, local ? cg.M : 1, local ? N : 0};
+    Dims d{cg.fpg, local ? N : cg.M * N, cg.fc * cg.fp, cg.fc * cg.fp, groups, 0, 0, local ? cg.M : 1, local ? N : 0};
     Epi ep{targets, cg.M * N, cg.fpg, 0, 0, scaleOutput, scaleTargets, biases, neuron, nullptr, 0, (unsigned)((size_t)F * cg.M * N * 4), 0};
     if (slabs && kChunk > 0 && !local) {   // split K: every chunk writes a plain slab, the caller reduces and applies the epilogue
         d.kChunk = kChunk;
@@ -866,7 +905,7 @@ int conv_img_acts_impl(const float* hidActs, const float* filters, float* target
     int chunks = 1;
     // unshared (img_acts.cu conv=false): one product per image pixel (batch = pixel), whose A operand gathers, tap
     // by tap, the filter bank of the module that sees the pixel at that tap (FiltTAddr)
-    Dims d{cg.fc, local ? N : H * W * N, cg.fp * cg.fpg, cg.fp * cg.fpg, groups, 0, local ? H * W : 1, local ? N : 0};
+    Dims d{cg.fc, local ? N : H * W * N, cg.fp * cg.fpg, cg.fp * cg.fpg, groups, 0, 0, local ? H * W : 1, local ? N : 0};
     Epi ep{targets, H * W * N, cg.fc, 0, 0, scaleOutput, scaleTargets, nullptr, MC_NEURON_NONE, nullptr, 0, (unsigned)((size_t)C * H * W * N * 4), 0};
     if (slabs && kChunk > 0 && !local) {
         d.kChunk = kChunk;
@@ -907,7 +946,7 @@ int conv_weight_acts_impl(const float* images, const float* hidActs, float* targ
         chunks = cg.M / partialSum;
         kChunk = partialSum * N;
     }
-    Dims d{cg.fc * cg.fp, cg.fpg, cg.M * N, kChunk, groups, 0, 1, 0};
+    Dims d{cg.fc * cg.fp, cg.fpg, cg.M * N, kChunk, groups, 0, 0, 1, 0};
     Epi ep{targets, F, 0, cg.fpg, (long)cg.fc * cg.fp * F, scaleOutput, scaleTargets, nullptr, MC_NEURON_NONE, nullptr, 0, (unsigned)((size_t)cg.fc * cg.fp * F * 4), 0};
     ConvP pa{images, cg.fc * cg.fp, (unsigned)((size_t)C * H * W * N * 4)};
     MatP pb{hidActs, cg.M * N, cg.fpg, cg.fpg * cg.M * N, (unsigned)((size_t)F * cg.M * N * 4), 0};  // hid[(g*fpg+f)*M*N + k]
@@ -940,7 +979,7 @@ int conv_split_plan(int rows, long cols, int K, int groups, int* kChunkOut) {
 int conv_weight_grad_plan(int N, int C, int F, int fs, int M, int groups, int* kChunkOut) {
     const int rows = (C / groups) * fs * fs, fpg = F / groups;
     const long K = (long)M * N;
-    Dims d{rows, fpg, (int)K, (int)K, groups, 0, 1, 0};
+    Dims d{rows, fpg, (int)K, (int)K, groups, 0, 0, 1, 0};
     static const int rowsOf[NTILES] = {32, 64, 96, 160, 128, 192}, colsOf[NTILES] = {128, 128, 128, 128, 192, 128};
     // the tile the static rule would take for a grid that fills the device
     const int t = heuristic_tile(d, ceil_div(num_cus(), (long)ceil_div(rows, 128) * ceil_div(fpg, 128) * groups));
@@ -967,7 +1006,7 @@ int gemm_impl(const float* A, const float* B, float* Cm, int m, int n, int k, in
         kChunk = (kChunk + 31) / 32 * 32;
         chunks = ceil_div(k, kChunk);
     }
-    Dims d{m, n, k, kChunk, 1, 0, 1, 0};
+    Dims d{m, n, k, kChunk, 1, 0, 0, 1, 0};
     Epi ep{Cm, ldc, 0, 0, chunkStride, alpha, beta, rowBias, neuron, mask, ldmask, (unsigned)(((size_t)(m - 1) * ldc + n) * 4),
            mask ? (unsigned)(((size_t)(m - 1) * ldmask + n) * 4) : 0u};
     // operand extents in bytes: (rows - 1) * ld + row length
