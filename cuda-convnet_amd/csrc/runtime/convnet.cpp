@@ -259,6 +259,12 @@ Layer* ConvNet::initLayer(const std::string& layerType, PyObject* paramsDict) {
     else if (layerType == "cnorm") l = new ContrastNormLayer(this, paramsDict);
     else if (layerType == "softmax") l = new SoftmaxLayer(this, paramsDict);
     else if (layerType == "eltsum") l = new EltwiseSumLayer(this, paramsDict);
+    else if (layerType == "eltmax") l = new EltwiseMaxLayer(this, paramsDict);
+    else if (layerType == "nailbed") l = new NailbedLayer(this, paramsDict);
+    else if (layerType == "blur") l = new GaussianBlurLayer(this, paramsDict);
+    else if (layerType == "resize") l = new ResizeLayer(this, paramsDict);
+    else if (layerType == "rgb2yuv") l = new RGBToYUVLayer(this, paramsDict);
+    else if (layerType == "rgb2lab") l = new RGBToLABLayer(this, paramsDict);
     else if (layerType == "neuron") l = new NeuronLayer(this, paramsDict);
     else if (layerType == "data") {
         DataLayer* d = new DataLayer(this, paramsDict);

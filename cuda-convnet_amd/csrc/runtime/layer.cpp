@@ -595,6 +595,101 @@ void EltwiseSumLayer::bpropActs(DevMat& v, int i, float scaleTargets, PASS_TYPE)
     else RT_MC(mc_axpby(tgt.data(), v.data(), scaleTargets, _coeffs->at(i), v.numel(), ST()));
 }
 
+// ==========================================================================================
+// Element-wise max                                                        (layer.cu:667-680)
+// ==========================================================================================
+void EltwiseMaxLayer::fpropActs(int i, float, PASS_TYPE) {
+    if (i == 1) RT_MC(mc_eltwise_max(_inputs[1]->data(), _inputs[0]->data(), getActs().data(), getActs().numel(), ST()));
+    else if (i > 1) RT_MC(mc_eltwise_max(getActs().data(), _inputs[i]->data(), getActs().data(), getActs().numel(), ST()));
+}
+
+void EltwiseMaxLayer::bpropActs(DevMat& v, int i, float scaleTargets, PASS_TYPE) {
+    RT_MC(mc_compute_eltwise_max_grad(v.data(), _inputs[i]->data(), getActs().data(), _prev[i]->getActsGrad().data(), scaleTargets != 0, v.numel(), ST()));
+}
+
+// ==========================================================================================
+// Image layers: nailbed, blur, resize, rgb2yuv, rgb2lab                   (layer.cu:770-867)
+// ==========================================================================================
+NailbedLayer::NailbedLayer(ConvNet* convNet, PyObject* paramsDict) : Layer(convNet, paramsDict) {
+    _channels = pyDictGetInt(paramsDict, "channels");
+    _start = pyDictGetInt(paramsDict, "start");
+    _stride = pyDictGetInt(paramsDict, "stride");
+    _outputsX = pyDictGetInt(paramsDict, "outputsX");
+    _imgSize = pyDictGetInt(paramsDict, "imgSize");
+}
+
+void NailbedLayer::fpropActs(int, float, PASS_TYPE) {
+    RT_MC(mc_conv_bed_of_nails(_inputs[0]->data(), getActs().data(), numCases(), _channels, _imgSize, _start, _stride, 0.f, 1.f, ST()));
+}
+
+void NailbedLayer::bpropActs(DevMat& v, int, float scaleTargets, PASS_TYPE) {
+    RT_MC(mc_conv_bed_of_nails_undo(v.data(), _prev[0]->getActsGrad().data(), numCases(), _channels, _imgSize, _start, _stride, scaleTargets, 1.f, ST()));
+}
+
+GaussianBlurLayer::GaussianBlurLayer(ConvNet* convNet, PyObject* paramsDict) : Layer(convNet, paramsDict) {
+    _channels = pyDictGetInt(paramsDict, "channels");
+    _imgSize = pyDictGetInt(paramsDict, "imgSize");
+    HostMat* h = pyDictGetMatrix(paramsDict, "filter");   // (1, filterSize)
+    if (h->rows() != 1 || h->cols() % 2 != 1) throw std::runtime_error(fmt("blur layer '%s': filter must be (1, odd), got %dx%d", _name.c_str(), h->rows(), h->cols()));
+    _taps.resize(h->numel());
+    h->toRowMajor(_taps.data());
+    _radius = h->cols() / 2;
+    h->release();
+    delete h;
+}
+
+void GaussianBlurLayer::copyToGPU() { _filter.copyFromHost(_taps.data(), 1, (int)_taps.size()); }
+
+void GaussianBlurLayer::fpropActs(int, float, PASS_TYPE) {
+    // rows into the output, then columns in place (layer.cu:796-799)
+    RT_MC(mc_conv_gaussian_blur(_inputs[0]->data(), _filter.data(), getActs().data(), numCases(), _channels, _imgSize, _radius, 1, 0.f, 1.f, ST()));
+    RT_MC(mc_conv_gaussian_blur(getActs().data(), _filter.data(), getActs().data(), numCases(), _channels, _imgSize, _radius, 0, 0.f, 1.f, ST()));
+}
+
+// The filter is symmetric, so the blur is its own transpose (layer.cu:801-807).
+void GaussianBlurLayer::bpropActs(DevMat& v, int, float scaleTargets, PASS_TYPE) {
+    DevMat& tgt = _prev[0]->getActsGrad();
+    DevMat& tgt1 = scaleTargets != 0 ? _actGradsTmp : tgt;
+    if (&tgt1 == &_actGradsTmp) _actGradsTmp.resize(v);
+    RT_MC(mc_conv_gaussian_blur(v.data(), _filter.data(), tgt1.data(), numCases(), _channels, _imgSize, _radius, 1, 0.f, 1.f, ST()));
+    RT_MC(mc_conv_gaussian_blur(tgt1.data(), _filter.data(), tgt.data(), numCases(), _channels, _imgSize, _radius, 0, scaleTargets, 1.f, ST()));
+}
+
+ResizeLayer::ResizeLayer(ConvNet* convNet, PyObject* paramsDict) : Layer(convNet, paramsDict) {
+    _channels = pyDictGetInt(paramsDict, "channels");
+    _imgSize = pyDictGetInt(paramsDict, "imgSize");
+    _tgtSize = pyDictGetInt(paramsDict, "tgtSize");
+    _scale = pyDictGetFloat(paramsDict, "scale");
+}
+
+void ResizeLayer::fpropActs(int, float, PASS_TYPE) {
+    RT_MC(mc_conv_resize_bilinear(_inputs[0]->data(), getActs().data(), numCases(), _channels, _imgSize, _tgtSize, _scale, ST()));
+}
+
+void ResizeLayer::bpropActs(DevMat&, int, float, PASS_TYPE) {   // layer.cu:829-832: "Can't do this"
+    throw std::runtime_error(fmt("resize layer '%s' has no backward pass", _name.c_str()));
+}
+
+RGBToYUVLayer::RGBToYUVLayer(ConvNet* convNet, PyObject* paramsDict) : Layer(convNet, paramsDict) {
+    _imgPixels = _numOutputs / 3;
+}
+
+void RGBToYUVLayer::fpropActs(int, float, PASS_TYPE) {
+    RT_MC(mc_conv_rgb_to_yuv(_inputs[0]->data(), getActs().data(), numCases(), _imgPixels, ST()));
+}
+
+void RGBToYUVLayer::bpropActs(DevMat&, int, float, PASS_TYPE) {   // layer.cu:846-849, 864-867
+    throw std::runtime_error(fmt("colour-transform layer '%s' has no backward pass", _name.c_str()));
+}
+
+RGBToLABLayer::RGBToLABLayer(ConvNet* convNet, PyObject* paramsDict) : RGBToYUVLayer(convNet, paramsDict) {
+    _center = pyDictGetInt(paramsDict, "center") != 0;
+}
+
+void RGBToLABLayer::fpropActs(int, float, PASS_TYPE) {
+    RT_MC(mc_conv_rgb_to_lab(_inputs[0]->data(), getActs().data(), numCases(), _imgPixels, _center, ST()));
+}
+
 DataLayer::DataLayer(ConvNet* convNet, PyObject* paramsDict) : Layer(convNet, paramsDict) {
     _dataIdx = pyDictGetInt(paramsDict, "dataIdx");
 }

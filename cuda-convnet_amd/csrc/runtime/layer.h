@@ -288,6 +288,71 @@ protected:
     floatv* _coeffs;
 };
 
+// layer.cuh:208-215, layer.cu:667-680
+class EltwiseMaxLayer : public Layer {
+public:
+    EltwiseMaxLayer(ConvNet* convNet, PyObject* paramsDict) : Layer(convNet, paramsDict) {}
+
+protected:
+    void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+};
+
+// Image-preprocessing layers (layer.cuh:267-328, layer.cu:770-867).  Resize and the colour transforms have no
+// backward pass (the reference asserts; its parser refuses gradient consumers below them, layer.py:399-403).
+class NailbedLayer : public Layer {
+public:
+    NailbedLayer(ConvNet* convNet, PyObject* paramsDict);
+
+protected:
+    void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    int _channels, _start, _stride, _outputsX, _imgSize;
+};
+
+class GaussianBlurLayer : public Layer {
+public:
+    GaussianBlurLayer(ConvNet* convNet, PyObject* paramsDict);
+    void copyToGPU() override;
+
+protected:
+    void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    int _channels, _imgSize, _radius;
+    std::vector<float> _taps;   // host copy of the (1, 2*radius+1) filter, taken in the constructor
+    DevMat _filter, _actGradsTmp;
+};
+
+class ResizeLayer : public Layer {
+public:
+    ResizeLayer(ConvNet* convNet, PyObject* paramsDict);
+
+protected:
+    void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    int _channels, _imgSize, _tgtSize;
+    float _scale;
+};
+
+class RGBToYUVLayer : public Layer {
+public:
+    RGBToYUVLayer(ConvNet* convNet, PyObject* paramsDict);
+
+protected:
+    void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    int _imgPixels;
+};
+
+class RGBToLABLayer : public RGBToYUVLayer {
+public:
+    RGBToLABLayer(ConvNet* convNet, PyObject* paramsDict);
+
+protected:
+    void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    bool _center;
+};
+
 class DataLayer : public Layer {
 public:
     DataLayer(ConvNet* convNet, PyObject* paramsDict);

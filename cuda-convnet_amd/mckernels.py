@@ -40,6 +40,14 @@ _SIGS = {
     "mc_conv_response_norm_undo": [c_fp] * 5 + [c_i] * 4 + [c_f] * 4 + [c_fp],
     "mc_conv_response_norm_cross_map": [c_fp] * 3 + [c_i] * 4 + [c_f, c_f, c_i, c_f, c_fp],
     "mc_conv_response_norm_cross_map_undo": [c_fp] * 5 + [c_i] * 4 + [c_f, c_f, c_i, c_f, c_f, c_fp],
+    "mc_conv_bed_of_nails": [c_fp, c_fp] + [c_i] * 5 + [c_f, c_f, c_fp],
+    "mc_conv_bed_of_nails_undo": [c_fp, c_fp] + [c_i] * 5 + [c_f, c_f, c_fp],
+    "mc_conv_gaussian_blur": [c_fp, c_fp, c_fp] + [c_i] * 5 + [c_f, c_f, c_fp],
+    "mc_conv_resize_bilinear": [c_fp, c_fp] + [c_i] * 4 + [c_f, c_fp],
+    "mc_conv_rgb_to_yuv": [c_fp, c_fp, c_i, c_i, c_fp],
+    "mc_conv_rgb_to_lab": [c_fp, c_fp, c_i, c_i, c_i, c_fp],
+    "mc_eltwise_max": [c_fp, c_fp, c_fp, c_sz, c_fp],
+    "mc_compute_eltwise_max_grad": [c_fp] * 4 + [c_i, c_sz, c_fp],
     "mc_neuron_activate": [c_i, c_f, c_f, c_fp, c_fp, c_sz, c_fp],
     "mc_neuron_input_grad": [c_i, c_f, c_f, c_fp, c_fp, c_fp, c_i, c_sz, c_fp],
     "mc_dropout_apply": [c_fp, c_fp, c_fp, c_f, c_i, c_sz, c_fp],

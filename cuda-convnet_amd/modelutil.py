@@ -18,6 +18,7 @@ NETS = {   # name -> (layer-def, layer-params, data dims, classes)
     "conv-local": ("layers-conv-local-13pct.cfg", "layer-params-conv-local-13pct.cfg", 3072, 10),
     "imagenet": ("imagenet.def", "imagenet.params", 150528, 100),
     "gc-small": ("gc-small.def", "gc-small.params", 432, 10),
+    "image-layers": ("image-layers.def", "image-layers.params", 768, 10),
 }
 
 

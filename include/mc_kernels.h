@@ -180,6 +180,42 @@ int mc_conv_response_norm_cross_map_undo(const float* outGrads, const float* den
                                          float addScale, float powScale, int blocked,
                                          float scaleTargets, float scaleOutput, mcStream_t stream);
 
+/* ---------------- image layers (nailbed, blur, resize, rgb2yuv, rgb2lab) ----------------
+ * Tensors are (channels, imgSize*imgSize, numImages), image index innermost, dense.
+ * convBedOfNails / convBedOfNailsUndo (conv_util.cu:667-676, kernel :463-537): output (oy, ox) is pixel
+ *   (startX + oy*strideX, startX + ox*strideX), outputsX = ceil(imgSize / strideX), strideX > 1.  The undo with
+ *   scaleTargets == 0 zeroes every non-nail pixel; with scaleTargets != 0 it touches the nail pixels only.
+ * convGaussianBlur (conv_util.cu:684-728, kernel :358-443): one direction of a separable blur,
+ *   out[x] = sum_d in[x+d]*filter[radius+d], zero outside the line; `filter` is 2*radius+1 floats on the
+ *   device, radius 1..4, imgSize >= 2*radius+1; target may be the same buffer as images.
+ * convResizeBilinear (conv_util.cu:2426-2474, kernel :290-341): source coordinate
+ *   clamp(px*scale + imgSize/2 - tgtSize/2*scale, 0, imgSize - 1.01).
+ * convRGBToYUV (conv_util.cu:2480-2524, kernel :172-194), convRGBToLAB (:2526-2601, kernel :237-268;
+ *   `center` subtracts 50 from L*): 3-channel inputs. */
+int mc_conv_bed_of_nails(const float* images, float* target, int numImages, int numChannels,
+                         int imgSize, int startX, int strideX, float scaleTargets, float scaleOutput,
+                         mcStream_t stream);
+int mc_conv_bed_of_nails_undo(const float* actsGrad, float* target, int numImages, int numChannels,
+                              int imgSize, int startX, int strideX, float scaleTargets,
+                              float scaleOutput, mcStream_t stream);
+int mc_conv_gaussian_blur(const float* images, const float* filter, float* target, int numImages,
+                          int numChannels, int imgSize, int radius, int horiz, float scaleTargets,
+                          float scaleOutput, mcStream_t stream);
+int mc_conv_resize_bilinear(const float* images, float* target, int numImages, int numChannels,
+                            int imgSize, int tgtSize, float scale, mcStream_t stream);
+int mc_conv_rgb_to_yuv(const float* images, float* target, int numImages, int imgPixels,
+                       mcStream_t stream);
+int mc_conv_rgb_to_lab(const float* images, float* target, int numImages, int imgPixels, int center,
+                       mcStream_t stream);
+
+/* ---------------- element-wise max layer ----------------
+ * EltwiseMaxLayer::fpropActs (Kernel/src/layers/layer.cu:670-676: applyBinary(NVMatrixAggs::Max)) and
+ * computeEltwiseMaxGrad (Kernel/src/layers/layer_kernels.cu:155-186):
+ * target = (add ? target : 0) + actGrad * (output == input). */
+int mc_eltwise_max(const float* a, const float* b, float* out, size_t n, mcStream_t stream);
+int mc_compute_eltwise_max_grad(const float* actGrad, const float* input, const float* output,
+                                float* target, int add, size_t n, mcStream_t stream);
+
 /* ---------------- neurons ----------------
  * Neuron functors of Kernel/include/layers/neuron.cuh:120-462 and the dropout neuron of
  * PluginsSrc/include/extralayers.cuh:34-102.  `a`,`b` are the neuron parameters

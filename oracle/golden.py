@@ -288,3 +288,128 @@ def sgd_update(w, inc, grad, eps, wc, mom):
     if wc > 0:
         inc += (np.float32(-wc * eps) * w).astype(np.float32)
     w += inc
+
+
+# --------------------------------------------------------------------------
+# image layers and element-wise max (NumPy)
+# --------------------------------------------------------------------------
+def _blend(target, value, scale_targets, scale_output):
+    value = np.float32(scale_output) * value.astype(np.float32)
+    if scale_targets == 0:
+        return value.astype(np.float32)
+    return (np.float32(scale_targets) * target + value).astype(np.float32)
+
+
+def bed_of_nails(imgs, N, C, img_size, start, stride, target=None, scale_targets=0.0, scale_output=1.0):
+    """convBedOfNails (Kernel/src/conv/conv_util.cu:667-670; kernel :463-537, forward branch):
+    output (oy, ox) = pixel (start + oy*stride, start + ox*stride), outputsX = DIVUP(imgSize, stride) (:554)."""
+    assert stride > 1                                   # conv_util.cu:552
+    ox = (img_size + stride - 1) // stride
+    x = imgs.reshape(C, img_size, img_size, N)
+    nails = x[:, start:start + (ox - 1) * stride + 1:stride, start:start + (ox - 1) * stride + 1:stride, :]
+    assert nails.shape[1] == ox and nails.shape[2] == ox
+    nails = nails.reshape(C * ox * ox, N)
+    return _blend(target, nails, scale_targets, scale_output)
+
+
+def bed_of_nails_undo(acts_grad, N, C, img_size, start, stride, target=None, scale_targets=0.0, scale_output=1.0):
+    """convBedOfNailsUndo (conv_util.cu:672-676; kernel reverse branch :502-533).  scaleTargets == 0: the target is
+    zeroed first (:563-565); otherwise only the nail pixels are updated, the rest of the target is left as is."""
+    assert stride > 1
+    ox = (img_size + stride - 1) // stride
+    g = acts_grad.reshape(C, ox, ox, N)
+    if scale_targets == 0:
+        out = np.zeros((C, img_size, img_size, N), np.float32)
+    else:
+        out = target.reshape(C, img_size, img_size, N).copy()
+    sl = (slice(None), slice(start, start + (ox - 1) * stride + 1, stride), slice(start, start + (ox - 1) * stride + 1, stride))
+    out[sl] = _blend(out[sl], g, scale_targets, scale_output)
+    return out.reshape(C * img_size * img_size, N)
+
+
+def _fma32(a, b, c):
+    """float32 fused multiply-add emulated in float64 (the product of two float32 is exact in float64)."""
+    return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(np.float32)
+
+
+def gaussian_blur(imgs, filt, N, C, img_size, horiz, target=None, scale_targets=0.0, scale_output=1.0):
+    """convGaussianBlur (conv_util.cu:684-728; kernel :358-443): one direction of the separable blur,
+    out[x] = sum_{d=-r..r} in[x+d] * filter[r+d] with zeros outside the line; the kernel adds the terms in
+    ascending x+d, each as a multiply-add.  The reference's filters are symmetric (layer.py:443-446), which
+    is the only case in which its prologue (filter[r+d]) and main loop (filter[r-d]) agree."""
+    f = np.asarray(filt, np.float32).reshape(-1)
+    r = f.size // 2
+    assert f.size == 2 * r + 1 and 1 <= r <= 4 and img_size >= 2 * r + 1      # conv_util.cu:692-693
+    x = imgs.reshape(C, img_size, img_size, N)
+    axis = 2 if horiz else 1
+    pad = [(0, 0)] * 4
+    pad[axis] = (r, r)
+    xp = np.pad(x, pad)
+    acc = np.zeros_like(x)
+    for k in range(2 * r + 1):
+        sl = [slice(None)] * 4
+        sl[axis] = slice(k, k + img_size)
+        acc = _fma32(f[k], xp[tuple(sl)], acc)
+    return _blend(target, acc.reshape(C * img_size * img_size, N), scale_targets, scale_output)
+
+
+def resize_bilinear(imgs, N, C, img_size, tgt_size, scale):
+    """convResizeBilinear (conv_util.cu:2426-2474; kernel :290-341)."""
+    f32 = np.float32
+    center_scale = f32(img_size * 0.5 - tgt_size * 0.5 * float(f32(scale)))      # double, then float (:2439-2441)
+    px = np.arange(tgt_size, dtype=np.float32)
+    src = np.maximum(f32(0), np.minimum(f32(img_size) - f32(1.01), _fma32(px, f32(scale), center_scale)))   # :314-315
+    fl = np.floor(src)
+    u = (np.floor(src + f32(1)) - src).astype(np.float32)      # weight of the left pixel (:317)
+    w = (src - fl).astype(np.float32)                          # weight of the bottom row (:318)
+    i0 = fl.astype(np.int64)
+    x = imgs.reshape(C, img_size, img_size, N)
+    iy, ix = i0[:, None], i0[None, :]
+    v0, v1 = x[:, iy, ix, :], x[:, iy, ix + 1, :]
+    v2, v3 = x[:, iy + 1, ix, :], x[:, iy + 1, ix + 1, :]
+    uu = u[None, None, :, None]
+    ww = w[None, :, None, None]
+    c0 = _fma32(uu, v0 - v1, v1)                               # :334
+    c1 = _fma32(uu, v2 - v3, v3)                               # :335
+    out = _fma32(ww, c1 - c0, c0)                              # :337
+    return out.reshape(C * tgt_size * tgt_size, N)
+
+
+def rgb_to_yuv(imgs, N, img_pixels):
+    """convRGBToYUV (conv_util.cu:2480-2524; kernel :172-194)."""
+    x = imgs.reshape(3, img_pixels, N).astype(np.float64)
+    m = np.array([[0.2126, 0.7152, 0.0722], [-0.09991, -0.33609, 0.436], [0.615, -0.55861, -0.05639]], np.float32).astype(np.float64)
+    return np.einsum("oc,cpn->opn", m, x).astype(np.float32).reshape(3 * img_pixels, N)
+
+
+def rgb_to_lab(imgs, N, img_pixels, center=False):
+    """convRGBToLAB (conv_util.cu:2526-2601; kernel :237-268, labf :196-201).  As in the kernel, the XYZ matrix
+    is applied WITHOUT the 5.6506753 factor its comment mentions, and the cube root is x ** 0.3333."""
+    x = imgs.reshape(3, img_pixels, N).astype(np.float64)
+    m = np.array([[0.49, 0.31, 0.2], [0.17697, 0.8124, 0.01063], [0.0, 0.01, 0.99]], np.float32).astype(np.float64)
+    xyz = np.einsum("oc,cpn->opn", m, x).astype(np.float32)
+
+    def labf(v):
+        v64 = v.astype(np.float64)
+        return np.where(v > np.float32(0.0088564517), np.power(np.maximum(v64, 1e-30), float(np.float32(0.3333))),
+                        float(np.float32(7.787037)) * v64 + float(np.float32(0.13793103))).astype(np.float32)
+
+    lx, ly, lz = labf(xyz[0]), labf(xyz[1]), labf(xyz[2])
+    L = np.float32(116.0) * ly - np.float32(16.0) - np.float32(50.0 if center else 0.0)
+    a = np.float32(500.0) * (lx - ly)
+    b = np.float32(200.0) * (ly - lz)
+    return np.stack([L, a, b]).astype(np.float32).reshape(3 * img_pixels, N)
+
+
+def eltwise_max(inputs):
+    """EltwiseMaxLayer::fpropActs (Kernel/src/layers/layer.cu:670-676)."""
+    out = np.maximum(inputs[0], inputs[1])
+    for x in inputs[2:]:
+        out = np.maximum(out, x)
+    return out.astype(np.float32)
+
+
+def eltwise_max_grad(act_grad, inp, out, target=None, add=False):
+    """computeEltwiseMaxGrad (Kernel/src/layers/layer_kernels.cu:155-186): grad * (output == input)."""
+    g = (act_grad * (out == inp)).astype(np.float32)
+    return (target + g).astype(np.float32) if add else g

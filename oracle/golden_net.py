@@ -112,6 +112,19 @@ class GoldenNet(object):
                 A[name] = G.softmax(ins[0])
             elif t == "eltsum":                                            # layer.cu:645-651
                 A[name] = sum(F32(c) * x for c, x in zip(l["coeffs"], ins)).astype(F32)
+            elif t == "eltmax":                                            # layer.cu:670-676
+                A[name] = G.eltwise_max(ins)
+            elif t == "nailbed":                                           # layer.cu:778-780
+                A[name] = G.bed_of_nails(ins[0], N, l["channels"], l["imgSize"], l["start"], l["stride"])
+            elif t == "blur":                                              # layer.cu:796-799: rows, then columns
+                h = G.gaussian_blur(ins[0], l["filter"], N, l["channels"], l["imgSize"], True)
+                A[name] = G.gaussian_blur(h, l["filter"], N, l["channels"], l["imgSize"], False)
+            elif t == "resize":                                            # layer.cu:825-827
+                A[name] = G.resize_bilinear(ins[0], N, l["channels"], l["imgSize"], l["tgtSize"], l["scale"])
+            elif t == "rgb2yuv":                                           # layer.cu:842-844
+                A[name] = G.rgb_to_yuv(ins[0], N, l["imgPixels"])
+            elif t == "rgb2lab":                                           # layer.cu:860-862
+                A[name] = G.rgb_to_lab(ins[0], N, l["imgPixels"], bool(l["center"]))
             elif t == "cost.logreg":                                       # layer.cu:993-1005
                 self.costs[name] = G.logreg_cost(ins[0], ins[1])
             elif t == "cost.sum2":                                         # layer.cu:1028-1032
@@ -236,6 +249,16 @@ class GoldenNet(object):
             elif t == "eltsum":
                 for i in range(len(inp)):
                     send(inp[i], F32(l["coeffs"][i]) * v)
+            elif t == "eltmax":                                            # layer.cu:678-680
+                for i in range(len(inp)):
+                    send(inp[i], G.eltwise_max_grad(v, ins[i], A[name]))
+            elif t == "nailbed":                                           # layer.cu:782-784
+                send(inp[0], G.bed_of_nails_undo(v, N, l["channels"], l["imgSize"], l["start"], l["stride"]))
+            elif t == "blur":                                              # layer.cu:803-807
+                h = G.gaussian_blur(v, l["filter"], N, l["channels"], l["imgSize"], True)
+                send(inp[0], G.gaussian_blur(h, l["filter"], N, l["channels"], l["imgSize"], False))
+            elif t in ("resize", "rgb2yuv", "rgb2lab"):                    # layer.cu:829-832, 846-849, 864-867
+                assert not self._grad_consumer(inp[0]), "no backward pass through " + t
             else:
                 raise NotImplementedError("golden net: layer type " + t)
         self.grads = g

@@ -66,7 +66,9 @@ def rel_l2(got, exp):
 # itself is bit-exact given equal inputs: test_kernels_gpu.py::test_pool_and_undo).  For that net
 # the comparison is one minibatch in the Frobenius norm.
 CASES = [("gc-small", 128 + 70, 128, "max"), ("nin-tiny", 128 + 70, 128, "max"), ("80sec", 128 + 36, 128, "max"),
-         ("18pct", 64, 64, "max"), ("conv-local", 34, 64, "l2")]
+         ("18pct", 64, 64, "max"), ("conv-local", 34, 64, "l2"),
+         # SURVEY 8f.3 layers: rgb2lab / rgb2yuv / blur / resize in front of two convs joined by eltmax, then blur + nailbed
+         ("image-layers", 64 + 22, 64, "max")]
 
 
 @pytest.mark.parametrize("net_name,cases,mini,metric", CASES)
@@ -120,6 +122,19 @@ def test_gradient_check_passes():
     got, out = run_child(net="gc-small", cases=32, mini=32, check_grads=1)
     assert int(got["failures"]) == 0, out[-2000:]
     assert "TESTS PASSED" in out
+
+
+def test_image_layers_forward_matches_oracle():
+    """Test-mode pass of the image-layers net: the activations of every new layer type against the oracle net
+    (last minibatch: a 22-case tail, the scalar code path of the kernels).  'lab' and 'emax' are not read back:
+    their sole consumers are the blur layers, which -- as in the reference (layer.py:307-323) -- write in place."""
+    names = ["yuv", "blur0", "resize", "blur1", "nails"]
+    got, _ = run_child(net="image-layers", cases=86, mini=64, test=1, acts=",".join(names))
+    net, layers, costs = oracle_run("image-layers", 86, 64, test=True)
+    for nm in names:
+        tol = 1e-5 if nm in ("yuv", "lab", "blur0", "resize") else 1e-4     # behind the convs: contraction tolerance
+        assert rel_rms(got["acts:" + nm], net.acts[nm]) < tol, nm
+    np.testing.assert_allclose(got["cost:logprob"], costs["logprob"], rtol=2e-4, atol=1e-3)
 
 
 def test_single_rank_rccl_path_is_identity():
