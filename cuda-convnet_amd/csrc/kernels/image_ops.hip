@@ -220,6 +220,65 @@ __global__ void k_eltwise_max_grad(const float* __restrict__ actGrad, const floa
     }
 }
 
+
+// ------------------------------------------------------------------ group sparsity over same-label cases (plugin cost.gsinlabel)
+// PluginsSrc/src/extrautils.cu: CalculateSqrtSumSquare :45-107 + MergeTemp :116-123, kCalculateGradient :167-199.
+// S[ch, j] = sqrt(count_j * sum_{n: label_n = value_j} sum_p acts[ch, p, n]^2); cost = sum S; the gradient of case n
+// is count * acts / (S[ch, label_n] + 2.5e-7).  Instead of the reference's sorted histogram of label values
+// (thrust, :4-31) each case finds its group by comparing labels, so S is kept PER CASE (sqrts[ch, n]).
+__global__ void k_gs_pixel_sumsq(const float* __restrict__ acts, float* q, int N, int channels, int P) {
+    const int total = channels * N;
+    for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
+        const int ch = item / N, n = item - ch * N;
+        const float* a = acts + (size_t)ch * P * N + n;
+        float s = 0.f;
+        for (int p = 0; p < P; ++p) {
+            const float v = a[(size_t)p * N];
+            s = fmaf(v, v, s);
+        }
+        q[item] = s;
+    }
+}
+
+// sqrts[ch, n] = S of n's label group; counts[n] = size of the group; costTerms[ch, n] = S for the first case of each
+// group and 0 for the others, so that sum(costTerms) is the cost with every group counted once.
+__global__ void k_gs_groups(const float* __restrict__ labels, const float* __restrict__ q, float* sqrts, float* counts, float* costTerms,
+                            int N, int channels) {
+    const int total = channels * N;
+    for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
+        const int ch = item / N, n = item - ch * N;
+        const float mine = labels[n];
+        float t = 0.f;
+        int c = 0;
+        bool first = true;
+        for (int m = 0; m < N; ++m)
+            if (labels[m] == mine) {
+                t += q[ch * N + m];
+                ++c;
+                first = first && m >= n;
+            }
+        const float sq = sqrtf((float)c * t);
+        sqrts[item] = sq;
+        costTerms[item] = first ? sq : 0.f;
+        if (ch == 0) counts[n] = (float)c;
+    }
+}
+
+template <int V>
+__global__ void k_gs_grad(const float* __restrict__ acts, const float* __restrict__ sqrts, const float* __restrict__ counts, float* target,
+                          int N, int channels, int P, float sT, float sO) {
+    typedef Vec<V> VV;
+    const int nChunks = N / V;
+    const size_t total = (size_t)channels * P * nChunks;
+    for (size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(item / nChunks), n = (int)(item - (size_t)row * nChunks) * V;
+        const int ch = row / P;
+        const typename VV::T g = map3(VV::ld(acts + (size_t)row * N + n), VV::ld(sqrts + (size_t)ch * N + n), VV::ld(counts + n),
+                                      [](float a, float s, float c) { return c * a / (s + 2.5e-7f); });
+        store_blend<V>(target + (size_t)row * N + n, g, sT, sO);
+    }
+}
+
 }  // namespace
 }  // namespace mc
 
@@ -349,6 +408,29 @@ int mc_compute_eltwise_max_grad(const float* actGrad, const float* input, const 
     else { if (v) MC_EMG(4, false); else MC_EMG(1, false); }
 #undef MC_EMG
     return launch_status("mc_compute_eltwise_max_grad");
+}
+
+int mc_group_sparsity_in_label_cost(const float* labels, const float* acts, float* pixelSumSq, float* sqrts, float* counts,
+                                    float* costTerms, int numCases, int channels, int imagePixels, mcStream_t s) {
+    MC_REQUIRE(labels && acts && pixelSumSq && sqrts && counts && costTerms, "mc_group_sparsity_in_label_cost: null pointer");
+    MC_REQUIRE(numCases > 0 && channels > 0 && imagePixels > 0, "mc_group_sparsity_in_label_cost: non-positive dimension");
+    MC_REQUIRE((size_t)channels * imagePixels * numCases < (1ull << 31), "mc_group_sparsity_in_label_cost: tensor exceeds 32-bit indexing");
+    dim3 g(grid_items((size_t)channels * numCases)), b(TPB);
+    hipLaunchKernelGGL(k_gs_pixel_sumsq, g, b, 0, S(s), acts, pixelSumSq, numCases, channels, imagePixels);
+    hipLaunchKernelGGL(k_gs_groups, g, b, 0, S(s), labels, pixelSumSq, sqrts, counts, costTerms, numCases, channels);
+    return launch_status("mc_group_sparsity_in_label_cost");
+}
+
+int mc_group_sparsity_in_label_grad(const float* acts, const float* sqrts, const float* counts, float* target, int numCases,
+                                    int channels, int imagePixels, float scaleTargets, float scaleOutput, mcStream_t s) {
+    MC_REQUIRE(acts && sqrts && counts && target, "mc_group_sparsity_in_label_grad: null pointer");
+    MC_REQUIRE(numCases > 0 && channels > 0 && imagePixels > 0, "mc_group_sparsity_in_label_grad: non-positive dimension");
+    MC_REQUIRE((size_t)channels * imagePixels * numCases < (1ull << 31), "mc_group_sparsity_in_label_grad: tensor exceeds 32-bit indexing");
+    const bool v = use_vec(numCases, {acts, sqrts, counts, target});
+    dim3 g(grid_items((size_t)channels * imagePixels * (numCases / (v ? 4 : 1)))), b(TPB);
+    if (v) hipLaunchKernelGGL(k_gs_grad<4>, g, b, 0, S(s), acts, sqrts, counts, target, numCases, channels, imagePixels, scaleTargets, scaleOutput);
+    else hipLaunchKernelGGL(k_gs_grad<1>, g, b, 0, S(s), acts, sqrts, counts, target, numCases, channels, imagePixels, scaleTargets, scaleOutput);
+    return launch_status("mc_group_sparsity_in_label_grad");
 }
 
 }  // extern "C"

@@ -2,8 +2,9 @@
 //   layer  "cccp"    : cascaded cross-channel parametric pooling (a 1x1 convolution over feature
 //                      maps), reference PluginsSrc/src/extralayers.cu:58-174
 //   neuron "dropout" : reference PluginsSrc/include/extralayers.cuh:34-102
-// Exports the two plugin entry points of the reference (extralayers.cu:200-215).  The
-// cost.gsinlabel layer of the reference's plugin is not provided (no shipped config uses it).
+//   cost   "cost.gsinlabel" : group sparsity over the cases that share a label,
+//                      reference PluginsSrc/src/extralayers.cu:5-46 + extrautils.cu
+// Exports the two plugin entry points of the reference (extralayers.cu:200-215).
 #include <stdlib.h>
 #include <iostream>
 
@@ -126,12 +127,51 @@ private:
     float _prob;
 };
 
+// Group sparsity in the label domain: inputs (labels, acts); for every channel and every distinct label of the
+// minibatch S = sqrt(count * sum of acts^2 over the label's cases and all pixels); cost = sum of S
+// (extralayers.cu:10-32), gradient -coeff * count * acts / (S + 2.5e-7) into the second input (:34-38).
+class GroupSparsityInLabelCostLayer : public CostLayer {
+public:
+    GroupSparsityInLabelCostLayer(ConvNet* convNet, PyObject* paramsDict) : CostLayer(convNet, paramsDict) {
+        _channels = pyDictGetInt(paramsDict, "channels");
+        _imgSize = pyDictGetInt(paramsDict, "imgSize");
+    }
+    int numCostValues() const override { return 1; }
+
+protected:
+    void fpropActs(int inpIdx, float, PASS_TYPE) override {
+        if (inpIdx != 0) return;   // both inputs are used together, once
+        DevMat& labels = *_inputs[0];
+        DevMat& acts = *_inputs[1];
+        const int N = labels.cols();
+        if (acts.rows() % _channels) throw std::runtime_error("cost.gsinlabel '" + _name + "': input rows are not a multiple of channels");
+        _pixels = acts.rows() / _channels;
+        _sumsq.resize(_channels, N);
+        _sqrts.resize(_channels, N);
+        _terms.resize(_channels, N);
+        _counts.resize(1, N);
+        RT_MC(mc_group_sparsity_in_label_cost(labels.data(), acts.data(), _sumsq.data(), _sqrts.data(), _counts.data(), _terms.data(), N, _channels,
+                                              _pixels, ST()));
+        RT_MC(mc_sum_all(_terms.data(), _terms.numel(), costSlot(), ST()));
+    }
+    void bpropActs(DevMat&, int inpIdx, float scaleTargets, PASS_TYPE) override {
+        if (inpIdx != 1) throw std::runtime_error("cost.gsinlabel: gradient requested for the label input");
+        DevMat& acts = *_inputs[1];
+        RT_MC(mc_group_sparsity_in_label_grad(acts.data(), _sqrts.data(), _counts.data(), _prev[1]->getActsGrad().data(), acts.cols(), _channels, _pixels,
+                                              scaleTargets, -_coeff, ST()));
+    }
+    int _channels, _imgSize, _pixels = 0;
+    DevMat _sumsq, _sqrts, _terms, _counts;
+};
+
 static Layer* CreateCCCPLayer(ConvNet* convNet, PyObject* paramsDict) { return new CCCPLayer(convNet, paramsDict); }
 static Neuron* CreateDropoutNeuron(PyObject* neuronParamsDict) { return new DropoutNeuron(neuronParamsDict); }
+static Layer* CreateGroupSparsityInLabelCostLayer(ConvNet* convNet, PyObject* paramsDict) { return new GroupSparsityInLabelCostLayer(convNet, paramsDict); }
 
 extern "C" __attribute__((visibility("default"))) std::map<std::string, layerConFunc> layerConstructor() {
     std::map<std::string, layerConFunc> ret;
     ret["cccp"] = &CreateCCCPLayer;
+    ret["cost.gsinlabel"] = &CreateGroupSparsityInLabelCostLayer;
     return ret;
 }
 

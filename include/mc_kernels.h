@@ -216,6 +216,21 @@ int mc_eltwise_max(const float* a, const float* b, float* out, size_t n, mcStrea
 int mc_compute_eltwise_max_grad(const float* actGrad, const float* input, const float* output,
                                 float* target, int add, size_t n, mcStream_t stream);
 
+/* ---------------- group sparsity over same-label cases (plugin cost.gsinlabel) ----------------
+ * CalculateSqrtSumSquareMatrix / CalculateGradient (PluginsSrc/src/extrautils.cu:128-158, 201-211).
+ * acts is (channels*imagePixels, numCases), labels (1, numCases).  For every channel and every distinct label
+ * value: S = sqrt(count * sum over the label's cases and all pixels of acts^2); the cost is the sum of all S.
+ * The cost call fills sqrts (channels, numCases: S of each case's own label), counts (numCases: size of the
+ * case's label group), costTerms (channels, numCases: S at the first case of each group, 0 elsewhere -- their
+ * sum is the cost) and uses pixelSumSq (channels, numCases) as scratch.
+ * The grad call: target = scaleTargets*target + scaleOutput * count*acts / (S + 2.5e-7). */
+int mc_group_sparsity_in_label_cost(const float* labels, const float* acts, float* pixelSumSq,
+                                    float* sqrts, float* counts, float* costTerms, int numCases,
+                                    int channels, int imagePixels, mcStream_t stream);
+int mc_group_sparsity_in_label_grad(const float* acts, const float* sqrts, const float* counts,
+                                    float* target, int numCases, int channels, int imagePixels,
+                                    float scaleTargets, float scaleOutput, mcStream_t stream);
+
 /* ---------------- neurons ----------------
  * Neuron functors of Kernel/include/layers/neuron.cuh:120-462 and the dropout neuron of
  * PluginsSrc/include/extralayers.cuh:34-102.  `a`,`b` are the neuron parameters

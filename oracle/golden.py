@@ -413,3 +413,31 @@ def eltwise_max_grad(act_grad, inp, out, target=None, add=False):
     """computeEltwiseMaxGrad (Kernel/src/layers/layer_kernels.cu:155-186): grad * (output == input)."""
     g = (act_grad * (out == inp)).astype(np.float32)
     return (target + g).astype(np.float32) if add else g
+
+
+def group_sparsity_in_label_cost(labels, acts, channels):
+    """GroupSparsityInLabelCostLayer::fpropActs (PluginsSrc/src/extralayers.cu:10-32) with
+    CalculateSqrtSumSquareMatrix (PluginsSrc/src/extrautils.cu:128-158): per channel and per distinct label value,
+    S = sqrt(count * sum over that label's cases and all pixels of acts^2); returns (cost = sum S, S per case
+    (channels, N), count per case (N,))."""
+    N = acts.shape[1]
+    lab = labels.reshape(-1)
+    q = (acts.reshape(channels, -1, N).astype(np.float64) ** 2).sum(axis=1)          # (channels, N)
+    same = lab[:, None] == lab[None, :]                                              # (N, N)
+    counts = same.sum(axis=1)
+    S = np.sqrt(counts[None, :] * (q @ same.astype(np.float64)))                     # S of case n's label, (channels, N)
+    first = np.array([not same[n, :n].any() for n in range(N)])
+    return float(S[:, first].sum()), S.astype(np.float32), counts.astype(np.float32)
+
+
+def group_sparsity_in_label_grad(labels, acts, channels, coeff, target=None, scale_targets=0.0):
+    """bpropActs (extralayers.cu:34-38) with kCalculateGradient (extrautils.cu:167-199):
+    actsGrad = scaleTargets*actsGrad - coeff * count * acts / (S + 2.5e-7)."""
+    N = acts.shape[1]
+    _, S, counts = group_sparsity_in_label_cost(labels, acts, channels)
+    a = acts.reshape(channels, -1, N).astype(np.float64)
+    g = (counts[None, None, :] * a / (S[:, None, :].astype(np.float64) + 2.5e-7)).reshape(acts.shape)
+    out = -float(coeff) * g
+    if scale_targets != 0:
+        out = scale_targets * target.astype(np.float64) + out
+    return out.astype(np.float32)

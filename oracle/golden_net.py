@@ -127,6 +127,8 @@ class GoldenNet(object):
                 A[name] = G.rgb_to_lab(ins[0], N, l["imgPixels"], bool(l["center"]))
             elif t == "cost.logreg":                                       # layer.cu:993-1005
                 self.costs[name] = G.logreg_cost(ins[0], ins[1])
+            elif t == "cost.gsinlabel":                                    # PluginsSrc/src/extralayers.cu:10-32
+                self.costs[name] = [G.group_sparsity_in_label_cost(ins[0], ins[1], l["channels"])[0]]
             elif t == "cost.sum2":                                         # layer.cu:1028-1032
                 self.costs[name] = [0.5 * float((ins[0].astype(np.float64) ** 2).sum())]
             else:
@@ -172,6 +174,8 @@ class GoldenNet(object):
                         send(inp[1], G.logreg_grad(A[L[inp[0]]["name"]], A[sm["name"]], l["coeff"]))
                     else:
                         g.setdefault(sm["name"], None)    # the softmax computes the fused gradient itself
+                elif t == "cost.gsinlabel":                                # PluginsSrc/src/extralayers.cu:34-38
+                    send(inp[1], G.group_sparsity_in_label_grad(A[L[inp[0]]["name"]], A[L[inp[1]]["name"]], l["channels"], l["coeff"]))
                 else:                                                      # layer.cu:1034-1036
                     send(inp[0], -F32(l["coeff"]) * A[L[inp[0]]["name"]])
                 continue

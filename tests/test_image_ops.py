@@ -118,3 +118,33 @@ def test_eltwise_max_and_grad_routing():
         np.testing.assert_array_equal(gr, np.where(x == out, g, 0))                       # every input equal to the max gets the gradient
     prev = rng.standard_normal(out.shape).astype(np.float32)
     np.testing.assert_array_equal(G.eltwise_max_grad(g, a, out, target=prev, add=True), prev + grads[0])
+
+
+def test_group_sparsity_in_label_cost_and_its_gradient():
+    """cost.gsinlabel (PluginsSrc/src/extrautils.cu): the cost by its definition over explicit label groups, and
+    the analytic gradient against central differences of that definition."""
+    rng = np.random.default_rng(6)
+    N, ch, P = 9, 3, 4
+    labels = np.array([[2, 0, 2, 5, 0, 2, 7, 5, 2]], np.float32)
+    acts = rng.standard_normal((ch * P, N)).astype(np.float32)
+
+    def cost_by_definition(a):
+        a = a.reshape(ch, P, N).astype(np.float64)
+        total = 0.0
+        for v in np.unique(labels):
+            cols = np.flatnonzero(labels[0] == v)
+            for c in range(ch):
+                total += np.sqrt(len(cols) * (a[c][:, cols] ** 2).sum())
+        return total
+
+    cost, S, counts = G.group_sparsity_in_label_cost(labels, acts, ch)
+    assert abs(cost - cost_by_definition(acts)) < 1e-9 * cost
+    np.testing.assert_array_equal(counts, [4, 2, 4, 2, 2, 4, 1, 2, 4])
+    g = G.group_sparsity_in_label_grad(labels, acts, ch, coeff=1.0)           # = -dCost/dActs
+    h = 1e-3
+    for idx in [(0, 0), (5, 3), (11, 6), (7, 8)]:
+        up, dn = acts.copy(), acts.copy()
+        up[idx] += h
+        dn[idx] -= h
+        num = (cost_by_definition(up) - cost_by_definition(dn)) / (up[idx].astype(np.float64) - dn[idx])
+        assert abs(-g[idx] - num) < 1e-3 * max(1.0, abs(num)), (idx, g[idx], num)

@@ -140,3 +140,23 @@ def test_image_ops_reject_bad_arguments():
     ]:
         with pytest.raises(m.McError):
             m.call(name, *args)
+
+
+@pytest.mark.parametrize("N,ch,P,classes", [(128, 8, 144, 10), (22, 3, 16, 4), (5, 2, 1, 5)])
+def test_group_sparsity_in_label_cost_and_grad(N, ch, P, classes):
+    m = mc()
+    rng = np.random.default_rng(36)
+    labels = rng.integers(0, classes, size=(1, N)).astype(np.float32)
+    acts = rng.standard_normal((ch * P, N)).astype(np.float32)
+    dl, da = dev(labels), dev(acts)
+    q, sq, terms, cnt = nans(ch, N), nans(ch, N), nans(ch, N), nans(1, N)
+    m.call("mc_group_sparsity_in_label_cost", ptr(dl), ptr(da), ptr(q), ptr(sq), ptr(cnt), ptr(terms), N, ch, P, None)
+    cost, S, counts = G.group_sparsity_in_label_cost(labels, acts, ch)
+    assert np.array_equal(host(cnt).reshape(-1), counts)
+    close(host(sq), S, 1e-5)
+    assert abs(float(host(terms).astype(np.float64).sum()) - cost) < 1e-5 * cost
+    for sT in (0.0, 1.0):
+        prev = rng.standard_normal(acts.shape).astype(np.float32)
+        t = nans(*acts.shape) if sT == 0 else dev(prev)
+        m.call("mc_group_sparsity_in_label_grad", ptr(da), ptr(sq), ptr(cnt), ptr(t), N, ch, P, sT, -0.5, None)
+        close(host(t), G.group_sparsity_in_label_grad(labels, acts, ch, 0.5, target=prev, scale_targets=sT), 1e-5)

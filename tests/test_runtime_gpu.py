@@ -80,7 +80,8 @@ def test_train_step_matches_oracle(net_name, cases, mini, metric):
         np.testing.assert_allclose(got["cost:" + k][0], v[0], rtol=2e-4, atol=1e-3)
         # the error count depends on exact ties between near-uniform class probabilities
         # (correctProb = 1/numMax, layer_kernels.cu:50-72): allow one case of slack
-        assert abs(got["cost:" + k][1] - v[1]) <= 1.0
+        if len(v) > 1:
+            assert abs(got["cost:" + k][1] - v[1]) <= 1.0
     worst, table, bad = 0.0, [], []
     for l in layers:
         if "weights" not in l:
