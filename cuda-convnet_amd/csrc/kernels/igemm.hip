@@ -457,18 +457,28 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         __builtin_amdgcn_s_setprio(3);
 #endif
         const __amdgpu_buffer_rsrc_t ra = make_rsrc(AADDR::base(pa), pa.bytes), rb = make_rsrc(BADDR::base(pb), pb.bytes);
+        auto produce = [&](auto persist_) {
+        constexpr bool PERSIST = decltype(persist_)::value;
         LA as[NS];
         LB bs[NS];
-        // fetches are issued in step order (u = 0, 1, 2, ...), so the (tile, K position) of the next one is a
-        // running pair of workgroup-uniform counters rather than a division of u
+        // Persistent workers (several column tiles per workgroup): fetches are issued in step order (u = 0, 1, 2, ...),
+        // so the (tile, K position) of the next one is a running pair of workgroup-uniform counters rather than a
+        // division of u.  One tile per workgroup (PERSIST false): the column origin is a loop invariant and the
+        // loaders' per-column decode stays hoisted out of the K loop (conv2 backward-data is bound by this arithmetic).
         int fk = 0, fj0 = coff + col_block(blockIdx.x) * BN, ft = blockIdx.x;
-        auto fetch = [&](auto& la, auto& lb, int) {
-            la.fetch(ra, pa, cg, g, b, kbeg + fk * BK, kend, i0, ilim, tid);
-            lb.fetch(rb, pb, cg, g, b, kbeg + fk * BK, kend, fj0, jlim, tid);
-            if (++fk == nkTile) {
-                fk = 0;
-                ft += gridDim.x;
-                fj0 = coff + col_block(ft) * BN;
+        const int j0c = fj0;
+        auto fetch = [&](auto& la, auto& lb, int u) {
+            if (PERSIST) {
+                la.fetch(ra, pa, cg, g, b, kbeg + fk * BK, kend, i0, ilim, tid);
+                lb.fetch(rb, pb, cg, g, b, kbeg + fk * BK, kend, fj0, jlim, tid);
+                if (++fk == nkTile) {
+                    fk = 0;
+                    ft += gridDim.x;
+                    fj0 = coff + col_block(ft) * BN;
+                }
+            } else {
+                la.fetch(ra, pa, cg, g, b, kbeg + u * BK, kend, i0, ilim, tid);
+                lb.fetch(rb, pb, cg, g, b, kbeg + u * BK, kend, j0c, jlim, tid);
             }
         };
         auto commit = [&](const auto& la, const auto& lb, int stage) {
@@ -534,6 +544,9 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
                 }
             }
         }
+        };
+        if ((int)gridDim.x == d.colTiles) produce(std::false_type{});
+        else produce(std::true_type{});
         return;
     }
 

@@ -27,26 +27,40 @@ def main():
     agg = collections.OrderedDict()
     q = ("select kernel_name, grid_size_x, grid_size_y, grid_size_z, workgroup_size_x, vgpr_count, accum_vgpr_count, "
          "lds_block_size, counter_name, value, duration, dispatch_id from counters_collection order by dispatch_id")
+    raw = collections.OrderedDict()
     for name, gx, gy, gz, wx, vg, ag, lds, cn, val, dur, did in cur.execute(q):
         if sub and sub not in name:
             continue
         key = (short(name)[:80], gx // max(wx, 1), gy, gz, vg, ag, lds)
-        d = agg.setdefault(key, {"n": set(), "dur": {}, "c": collections.defaultdict(list)})
-        d["n"].add(did)
-        d["dur"][did] = dur
-        d["c"][cn].append(val)
-    for key, d in agg.items():
-        durs = list(d["dur"].values())
-        out.write("%s  grid=(%d,%d,%d) vgpr=%d agpr=%d lds=%d  launches=%d  avg_us(profiled)=%.1f\n"
-                  % (key + (len(d["n"]), sum(durs) / len(durs) / 1e3)))
-        for c, v in sorted(d["c"].items()):
-            mean = sum(v) / len(v)
-            extra = ""
-            if c == "FETCH_SIZE":
-                extra = "  -> %.3f MB per launch (KiB x 1024 x 2, gfx950 correction)" % (mean * 1024 * 2 / 1e6)
-            elif c == "WRITE_SIZE":
-                extra = "  -> %.3f MB per launch (KiB x 1024)" % (mean * 1024 / 1e6)
-            out.write("   %-28s mean=%.6g%s\n" % (c, mean, extra))
+        d = raw.setdefault(key, collections.OrderedDict())
+        e = d.setdefault(did, {"dur": dur, "c": {}})
+        e["c"][cn] = val
+    # Persistent column workers cap grid.x at the resident-workgroup count, so launches of one instantiation for
+    # DIFFERENT layers can share a grid (conv1 and conv2 forward both run (256,1,1)): split a group further into
+    # "shapes" by duration (a new shape starts where the sorted durations jump by more than 1.6x).
+    for key, d in raw.items():
+        order = sorted(d, key=lambda i: d[i]["dur"])
+        shapes, lo = [], None
+        for i in order:
+            if lo is None or d[i]["dur"] > 1.6 * lo:
+                shapes.append([])
+                lo = d[i]["dur"]
+            shapes[-1].append(i)
+        for si, ids in enumerate(shapes):
+            durs = [d[i]["dur"] for i in ids]
+            tag = "" if len(shapes) == 1 else "  shape %d/%d" % (si + 1, len(shapes))
+            out.write("%s  grid=(%d,%d,%d) vgpr=%d agpr=%d lds=%d  launches=%d  avg_us(profiled)=%.1f%s\n"
+                      % (key + (len(ids), sum(durs) / len(durs) / 1e3, tag)))
+            names = sorted({c for i in ids for c in d[i]["c"]})
+            for c in names:
+                v = [d[i]["c"][c] for i in ids if c in d[i]["c"]]
+                mean = sum(v) / len(v)
+                extra = ""
+                if c == "FETCH_SIZE":
+                    extra = "  -> %.3f MB per launch (KiB x 1024 x 2, gfx950 correction)" % (mean * 1024 * 2 / 1e6)
+                elif c == "WRITE_SIZE":
+                    extra = "  -> %.3f MB per launch (KiB x 1024)" % (mean * 1024 / 1e6)
+                out.write("   %-28s mean=%.6g%s\n" % (c, mean, extra))
 
 
 if __name__ == "__main__":

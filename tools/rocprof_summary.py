@@ -26,8 +26,27 @@ with open(out, "w") as f:
         f.write("%-100s %8d %14.1f %12.3f %6.2f%%\n" % (short(name)[:100], calls, total, avg, pct))
     f.write("\n# the same trace split by launch shape (grid in workgroups); registers and LDS per workgroup\n")
     f.write("%-72s %-16s %6s %12s %12s %5s %7s\n" % ("kernel", "grid", "calls", "avg_us", "total_us", "vgpr", "lds"))
-    q = ("select name, grid_x / workgroup_x, grid_y / workgroup_y, grid_z / workgroup_z, count(*), avg(duration) / 1e3, "
-         "sum(duration) / 1e3, max(vgpr_count), max(lds_size) from kernels group by name, grid_x, grid_y, grid_z order by 7 desc")
-    for name, gx, gy, gz, calls, avg, total, vgpr, lds in cur.execute(q):
-        f.write("%-72s %-16s %6d %12.3f %12.1f %5d %7d\n" % (short(name)[:72], "(%d,%d,%d)" % (gx, gy, gz), calls, avg, total, vgpr, lds))
+    # One instantiation serves several layers, and persistent column workers cap grid.x at the resident-workgroup
+    # count, so two layers can even share a grid: launches of one (kernel, grid) are split further into shapes
+    # wherever the sorted durations jump by more than 1.6x.
+    q = ("select name, grid_x / workgroup_x, grid_y / workgroup_y, grid_z / workgroup_z, duration, vgpr_count, lds_size from kernels")
+    groups = {}
+    for name, gx, gy, gz, dur, vgpr, lds in cur.execute(q):
+        groups.setdefault((name, gx, gy, gz), []).append((dur, vgpr, lds))
+    lines = []
+    for (name, gx, gy, gz), ls in groups.items():
+        ls.sort()
+        shapes, lo = [], None
+        for e in ls:
+            if lo is None or e[0] > 1.6 * lo:
+                shapes.append([])
+                lo = e[0]
+            shapes[-1].append(e)
+        for si, sh in enumerate(shapes):
+            total = sum(e[0] for e in sh) / 1e3
+            grid = "(%d,%d,%d)" % (gx, gy, gz) + ("" if len(shapes) == 1 else " #%d" % (si + 1))
+            lines.append((total, "%-72s %-16s %6d %12.3f %12.1f %5d %7d\n" % (short(name)[:72], grid, len(sh), total / len(sh), total,
+                                                                            max(e[1] for e in sh), max(e[2] for e in sh))))
+    for _, line in sorted(lines, reverse=True):
+        f.write(line)
 print(open(out).read()[:6000])
