@@ -279,6 +279,45 @@ __global__ void k_gs_grad(const float* __restrict__ acts, const float* __restric
     }
 }
 
+
+// ------------------------------------------------------------------ channel gather / scatter (random sparse connectivity)
+// The reference's *Sparse conv kernels (filter_acts.cu:259-413, img_acts.cu:266-470, weight_acts.cu:256-409) read
+// channel colorIndices[g*filterChannels + c] where the dense ones read channel g*filterChannels + c.  Here the
+// connected channels are gathered into a dense (groups*filterChannels)-channel tensor, the dense grouped
+// contraction runs on it (MFMA engine, unchanged), and the backward-data result is summed back per real channel.
+template <int V>
+__global__ void k_gather_channels(const float* __restrict__ src, const int* __restrict__ idx, float* dst, int N, int K, int P, int numSrc) {
+    typedef Vec<V> VV;
+    const int nChunks = N / V;
+    const size_t total = (size_t)K * P * nChunks;
+    for (size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(item / nChunks), n = (int)(item - (size_t)row * nChunks) * V;
+        const int k = row / P, p = row - k * P;
+        const int c = idx[k];
+        VV::st(dst + (size_t)row * N + n, (unsigned)c < (unsigned)numSrc ? VV::ld(src + ((size_t)c * P + p) * N + n) : VV::splat(0.f));
+    }
+}
+
+// dst[c] = sT*dst[c] + sO * sum_{o < O} src[inv[c*O + o]], terms added in ascending o
+template <int V>
+__global__ void k_scatter_channels(const float* __restrict__ src, const int* __restrict__ inv, float* dst, int N, int C, int O, int P,
+                                   int numSrc, float sT, float sO) {
+    typedef Vec<V> VV;
+    const int nChunks = N / V;
+    const size_t total = (size_t)C * P * nChunks;
+    for (size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(item / nChunks), n = (int)(item - (size_t)row * nChunks) * V;
+        const int c = row / P, p = row - c * P;
+        typename VV::T acc = VV::splat(0.f);
+        for (int o = 0; o < O; ++o) {
+            const int k = inv[c * O + o];
+            if ((unsigned)k < (unsigned)numSrc)
+                acc = map2(acc, VV::ld(src + ((size_t)k * P + p) * N + n), [](float a, float b) { return a + b; });
+        }
+        store_blend<V>(dst + (size_t)row * N + n, acc, sT, sO);
+    }
+}
+
 }  // namespace
 }  // namespace mc
 
@@ -431,6 +470,33 @@ int mc_group_sparsity_in_label_grad(const float* acts, const float* sqrts, const
     if (v) hipLaunchKernelGGL(k_gs_grad<4>, g, b, 0, S(s), acts, sqrts, counts, target, numCases, channels, imagePixels, scaleTargets, scaleOutput);
     else hipLaunchKernelGGL(k_gs_grad<1>, g, b, 0, S(s), acts, sqrts, counts, target, numCases, channels, imagePixels, scaleTargets, scaleOutput);
     return launch_status("mc_group_sparsity_in_label_grad");
+}
+
+int mc_conv_gather_channels(const float* images, const int* channelIndices, float* target, int numImages, int numImgColors,
+                            int numIndices, int imgPixels, mcStream_t s) {
+    MC_REQUIRE(images && channelIndices && target, "mc_conv_gather_channels: null pointer");
+    MC_REQUIRE(images != target, "mc_conv_gather_channels: target must not alias images");
+    MC_REQUIRE(numImages > 0 && numImgColors > 0 && numIndices > 0 && imgPixels > 0, "mc_conv_gather_channels: non-positive dimension");
+    MC_REQUIRE((size_t)numImgColors * imgPixels * numImages < (1ull << 31) && (size_t)numIndices * imgPixels * numImages < (1ull << 31),
+               "mc_conv_gather_channels: tensor exceeds 32-bit indexing");
+    const bool v = use_vec(numImages, {images, target});
+    dim3 g(grid_items((size_t)numIndices * imgPixels * (numImages / (v ? 4 : 1)))), b(TPB);
+    if (v) hipLaunchKernelGGL(k_gather_channels<4>, g, b, 0, S(s), images, channelIndices, target, numImages, numIndices, imgPixels, numImgColors);
+    else hipLaunchKernelGGL(k_gather_channels<1>, g, b, 0, S(s), images, channelIndices, target, numImages, numIndices, imgPixels, numImgColors);
+    return launch_status("mc_conv_gather_channels");
+}
+
+int mc_conv_scatter_channels(const float* gathered, const int* inverseIndices, float* target, int numImages, int numImgColors,
+                             int overSample, int imgPixels, float scaleTargets, float scaleOutput, mcStream_t s) {
+    MC_REQUIRE(gathered && inverseIndices && target, "mc_conv_scatter_channels: null pointer");
+    MC_REQUIRE(gathered != target, "mc_conv_scatter_channels: target must not alias the gathered tensor");
+    MC_REQUIRE(numImages > 0 && numImgColors > 0 && overSample > 0 && imgPixels > 0, "mc_conv_scatter_channels: non-positive dimension");
+    MC_REQUIRE((size_t)numImgColors * overSample * imgPixels * numImages < (1ull << 31), "mc_conv_scatter_channels: tensor exceeds 32-bit indexing");
+    const bool v = use_vec(numImages, {gathered, target});
+    dim3 g(grid_items((size_t)numImgColors * imgPixels * (numImages / (v ? 4 : 1)))), b(TPB);
+    if (v) hipLaunchKernelGGL(k_scatter_channels<4>, g, b, 0, S(s), gathered, inverseIndices, target, numImages, numImgColors, overSample, imgPixels, numImgColors * overSample, scaleTargets, scaleOutput);
+    else hipLaunchKernelGGL(k_scatter_channels<1>, g, b, 0, S(s), gathered, inverseIndices, target, numImages, numImgColors, overSample, imgPixels, numImgColors * overSample, scaleTargets, scaleOutput);
+    return launch_status("mc_conv_scatter_channels");
 }
 
 }  // extern "C"

@@ -489,15 +489,72 @@ LocalLayer::LocalLayer(ConvNet* convNet, PyObject* paramsDict) : WeightLayer(con
     _numFilters = pyDictGetInt(paramsDict, "filters");
     _modulesX = pyDictGetInt(paramsDict, "modulesX");
     _modules = pyDictGetInt(paramsDict, "modules");
-    for (int rs : *_randSparse)
-        if (rs) throw std::runtime_error(fmt("layer '%s': randSparse connectivity is not supported by this runtime", _name.c_str()));
+    const size_t ni = _randSparse->size();
+    _conns.resize(ni);
+    _inverse.resize(ni);
+    _dConns.assign(ni, nullptr);
+    _dInverse.assign(ni, nullptr);
+    _gathered.assign(ni, nullptr);
+    _gatheredGrad.assign(ni, nullptr);
+    PyObject* pyConns = PyDict_GetItemString(paramsDict, "filterConns");
+    for (size_t i = 0; i < ni; i++) {
+        if (!_randSparse->at(i)) continue;
+        PyObject* li = (pyConns && PyList_Check(pyConns) && (size_t)PyList_GET_SIZE(pyConns) > i) ? PyList_GET_ITEM(pyConns, i) : nullptr;
+        const int C = _channels->at(i), K = _groups->at(i) * _filterChannels->at(i), O = _overSample->at(i);
+        if (!li || !PyList_Check(li) || PyList_GET_SIZE(li) != K || O < 1 || O * C != K)
+            throw std::runtime_error(fmt("layer '%s'[%zu]: randSparse needs filterConns of length groups*filterChannels = %d = overSample*channels", _name.c_str(), i, K));
+        std::vector<int>& conns = _conns[i];
+        std::vector<int>& inv = _inverse[i];
+        conns.resize(K);
+        inv.assign((size_t)C * O, -1);
+        std::vector<int> seen(C, 0);
+        for (int k = 0; k < K; k++) {
+            const long c = PyLong_AsLong(PyList_GET_ITEM(li, k));
+            if (c < 0 || c >= C) throw std::runtime_error(fmt("layer '%s'[%zu]: filterConns[%d] = %ld is not a channel index", _name.c_str(), i, k, c));
+            conns[k] = (int)c;
+            // every block of `channels` consecutive entries is a permutation (layer.py:860): each channel is copied
+            // exactly overSample times, in ascending k
+            if (seen[c] >= O) throw std::runtime_error(fmt("layer '%s'[%zu]: channel %ld is connected more than overSample = %d times", _name.c_str(), i, c, O));
+            inv[(size_t)c * O + seen[c]++] = k;
+        }
+        _gathered[i] = new DevMat();
+        _gatheredGrad[i] = new DevMat();
+    }
 }
 
 LocalLayer::~LocalLayer() {
     for (intv* v : {_padding, _stride, _filterSize, _channels, _imgSize, _groups, _filterChannels, _randSparse, _overSample, _filterPixels, _imgPixels}) delete v;
+    for (int* p : _dConns) if (p) (void)hipFree(p);
+    for (int* p : _dInverse) if (p) (void)hipFree(p);
+    for (DevMat* m : _gathered) delete m;
+    for (DevMat* m : _gatheredGrad) delete m;
 }
 
-#define CONV_GEOM(i) numCases(), _channels->at(i), _imgSize->at(i), _imgSize->at(i), _numFilters, _filterSize->at(i), _padding->at(i), _stride->at(i), _modulesX, _modulesX, _groups->at(i)
+void LocalLayer::copyToGPU() {
+    WeightLayer::copyToGPU();
+    for (size_t i = 0; i < _conns.size(); i++) {
+        if (_conns[i].empty() || _dConns[i]) continue;
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&_dConns[i]), _conns[i].size() * sizeof(int)));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&_dInverse[i]), _inverse[i].size() * sizeof(int)));
+        RT_HIP(hipMemcpy(_dConns[i], _conns[i].data(), _conns[i].size() * sizeof(int), hipMemcpyHostToDevice));
+        RT_HIP(hipMemcpy(_dInverse[i], _inverse[i].data(), _inverse[i].size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+}
+
+const float* LocalLayer::sparseInput(int i, const DevMat& input) {
+    DevMat& g = *_gathered[i];
+    g.resize(sparseChannels(i) * _imgPixels->at(i), input.cols());
+    RT_MC(mc_conv_gather_channels(input.data(), _dConns[i], g.data(), input.cols(), _channels->at(i), sparseChannels(i), _imgPixels->at(i), ST()));
+    return g.data();
+}
+
+void LocalLayer::sparseScatter(int i, const DevMat& gathered, DevMat& target, float scaleTargets) {
+    RT_MC(mc_conv_scatter_channels(gathered.data(), _dInverse[i], target.data(), gathered.cols(), _channels->at(i), _overSample->at(i), _imgPixels->at(i),
+                                   scaleTargets, 1.f, ST()));
+}
+
+// dense inputs: the layer's channels; sparse inputs: the gathered tensor's groups*filterChannels channels
+#define CONV_GEOM(i) numCases(), (sparse(i) ? sparseChannels(i) : _channels->at(i)), _imgSize->at(i), _imgSize->at(i), _numFilters, _filterSize->at(i), _padding->at(i), _stride->at(i), _modulesX, _modulesX, _groups->at(i)
 
 ConvLayer::ConvLayer(ConvNet* convNet, PyObject* paramsDict) : LocalLayer(convNet, paramsDict) {
     _partialSum = pyDictGetInt(paramsDict, "partialSum");
@@ -510,7 +567,8 @@ void ConvLayer::fpropActs(int i, float scaleTargets, PASS_TYPE) {
     const bool first = scaleTargets == 0;
     NeuronLayer* relu = _sharedBiases ? fusableRelu() : nullptr;
     if (relu) relu->setFusedIntoProducer(true);
-    RT_MC(mc_conv_filter_acts_fused(_inputs[i]->data(), _weights[i].getW(), getActs().data(), (first && _sharedBiases) ? _biases->getW() : nullptr,
+    const float* in = sparse(i) ? sparseInput(i, *_inputs[i]) : _inputs[i]->data();
+    RT_MC(mc_conv_filter_acts_fused(in, _weights[i].getW(), getActs().data(), (first && _sharedBiases) ? _biases->getW() : nullptr,
                                     relu ? MC_NEURON_RELU : MC_NEURON_NONE, CONV_GEOM(i), scaleTargets, 1.f, ST()));
     if (first && !_sharedBiases) RT_MC(mc_add_row_vector(getActs().data(), _biases->getW(), _numFilters * _modules, numCases(), 1.f, ST()));
 }
@@ -528,19 +586,30 @@ void ConvLayer::bpropWeights(DevMat& v, int i, PASS_TYPE passType) {
     // chunks need not be whole modules.
     const float scale = passType == PASS_GC ? 1.f : _weights[i].getEps() / _convNet->gradScaleCases(numCases());
     const float scaleTargets = _weights[i].getNumUpdates() > 0 ? 1.f : 0.f;
-    const size_t wsb = mc_conv_weight_grad_workspace_bytes(numCases(), _channels->at(i), _numFilters, _filterSize->at(i), _modules, _groups->at(i));
-    RT_MC(mc_conv_weight_grad(_prev[i]->getActs().data(), v.data(), _weights[i].getGrad(), CONV_GEOM(i), scaleTargets, scale,
+    const size_t wsb = mc_conv_weight_grad_workspace_bytes(numCases(), sparse(i) ? sparseChannels(i) : _channels->at(i), _numFilters, _filterSize->at(i),
+                                                           _modules, _groups->at(i));
+    // a sparse input was gathered by fpropActs; the gathered tensor is the layer's own and still holds this minibatch
+    const float* in = sparse(i) ? _gathered[i]->data() : _prev[i]->getActs().data();
+    RT_MC(mc_conv_weight_grad(in, v.data(), _weights[i].getGrad(), CONV_GEOM(i), scaleTargets, scale,
                               wsb ? workspace(wsb) : nullptr, wsb, ST()));
 }
 
 void ConvLayer::bpropActs(DevMat& v, int i, float scaleTargets, PASS_TYPE) {
+    if (sparse(i)) {   // layer.cu:526-535: gradient of every connected copy, then the sum over the copies of a channel
+        DevMat& tmp = *_gatheredGrad[i];
+        tmp.resize(sparseChannels(i) * _imgPixels->at(i), numCases());
+        RT_MC(mc_conv_img_acts(v.data(), _weights[i].getW(), tmp.data(), CONV_GEOM(i), 0.f, 1.f, ST()));
+        sparseScatter(i, tmp, _prev[i]->getActsGrad(), scaleTargets);
+        return;
+    }
     RT_MC(mc_conv_img_acts(v.data(), _weights[i].getW(), _prev[i]->getActsGrad().data(), CONV_GEOM(i), scaleTargets, 1.f, ST()));
 }
 
 LocalUnsharedLayer::LocalUnsharedLayer(ConvNet* convNet, PyObject* paramsDict) : LocalLayer(convNet, paramsDict) {}
 
 void LocalUnsharedLayer::fpropActs(int i, float scaleTargets, PASS_TYPE) {
-    RT_MC(mc_local_filter_acts(_inputs[i]->data(), _weights[i].getW(), getActs().data(), CONV_GEOM(i), scaleTargets, 1.f, ST()));
+    const float* in = sparse(i) ? sparseInput(i, *_inputs[i]) : _inputs[i]->data();
+    RT_MC(mc_local_filter_acts(in, _weights[i].getW(), getActs().data(), CONV_GEOM(i), scaleTargets, 1.f, ST()));
     if (scaleTargets == 0) RT_MC(mc_add_row_vector(getActs().data(), _biases->getW(), _numFilters * _modules, numCases(), 1.f, ST()));
 }
 
@@ -552,10 +621,18 @@ void LocalUnsharedLayer::bpropBiases(DevMat& v, PASS_TYPE passType) {
 void LocalUnsharedLayer::bpropWeights(DevMat& v, int i, PASS_TYPE passType) {
     const float scale = passType == PASS_GC ? 1.f : _weights[i].getEps() / _convNet->gradScaleCases(numCases());
     const float scaleTargets = _weights[i].getNumUpdates() > 0 ? 1.f : 0.f;
-    RT_MC(mc_local_weight_acts(_prev[i]->getActs().data(), v.data(), _weights[i].getGrad(), CONV_GEOM(i), scaleTargets, scale, ST()));
+    const float* in = sparse(i) ? _gathered[i]->data() : _prev[i]->getActs().data();
+    RT_MC(mc_local_weight_acts(in, v.data(), _weights[i].getGrad(), CONV_GEOM(i), scaleTargets, scale, ST()));
 }
 
 void LocalUnsharedLayer::bpropActs(DevMat& v, int i, float scaleTargets, PASS_TYPE) {
+    if (sparse(i)) {
+        DevMat& tmp = *_gatheredGrad[i];
+        tmp.resize(sparseChannels(i) * _imgPixels->at(i), numCases());
+        RT_MC(mc_local_img_acts(v.data(), _weights[i].getW(), tmp.data(), CONV_GEOM(i), 0.f, 1.f, ST()));
+        sparseScatter(i, tmp, _prev[i]->getActsGrad(), scaleTargets);
+        return;
+    }
     RT_MC(mc_local_img_acts(v.data(), _weights[i].getW(), _prev[i]->getActsGrad().data(), CONV_GEOM(i), scaleTargets, 1.f, ST()));
 }
 

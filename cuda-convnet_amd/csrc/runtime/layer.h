@@ -238,10 +238,24 @@ public:
     LocalLayer(ConvNet* convNet, PyObject* paramsDict);
     ~LocalLayer();
 
+    void copyToGPU() override;
+
 protected:
+    // Random sparse connectivity (layer.cu:437-457; filterConns of Python/layer.py:848-871): input i's filter group g
+    // sees channels filterConns[i][g*filterChannels + c].  sparseInput(i) gathers those channels into a dense
+    // (groups*filterChannels)-channel tensor the grouped contractions run on; sparseChannels(i) is its channel count.
+    bool sparse(int i) const { return _randSparse->at(i) != 0; }
+    int sparseChannels(int i) const { return _groups->at(i) * _filterChannels->at(i); }
+    const float* sparseInput(int i, const DevMat& input);
+    // backward data of a sparse input: `gathered` holds the gradient of the gathered tensor
+    void sparseScatter(int i, const DevMat& gathered, DevMat& target, float scaleTargets);
+
     intv *_padding, *_stride, *_filterSize, *_channels, *_imgSize, *_groups;
     intv *_imgPixels, *_filterPixels, *_filterChannels, *_overSample, *_randSparse;
     int _modulesX, _modules, _numFilters;
+    std::vector<std::vector<int>> _conns, _inverse;   // per input; empty when dense
+    std::vector<int*> _dConns, _dInverse;             // device copies
+    std::vector<DevMat*> _gathered, _gatheredGrad;
 };
 
 class ConvLayer : public LocalLayer {

@@ -48,6 +48,8 @@ _SIGS = {
     "mc_conv_rgb_to_lab": [c_fp, c_fp, c_i, c_i, c_i, c_fp],
     "mc_eltwise_max": [c_fp, c_fp, c_fp, c_sz, c_fp],
     "mc_compute_eltwise_max_grad": [c_fp] * 4 + [c_i, c_sz, c_fp],
+    "mc_conv_gather_channels": [c_fp, c_fp, c_fp] + [c_i] * 4 + [c_fp],
+    "mc_conv_scatter_channels": [c_fp, c_fp, c_fp] + [c_i] * 4 + [c_f, c_f, c_fp],
     "mc_group_sparsity_in_label_cost": [c_fp] * 6 + [c_i] * 3 + [c_fp],
     "mc_group_sparsity_in_label_grad": [c_fp] * 4 + [c_i] * 3 + [c_f, c_f, c_fp],
     "mc_neuron_activate": [c_i, c_f, c_f, c_fp, c_fp, c_sz, c_fp],

@@ -19,6 +19,7 @@ NETS = {   # name -> (layer-def, layer-params, data dims, classes)
     "imagenet": ("imagenet.def", "imagenet.params", 150528, 100),
     "gc-small": ("gc-small.def", "gc-small.params", 432, 10),
     "image-layers": ("image-layers.def", "image-layers.params", 768, 10),
+    "gc-sparse": ("gc-sparse.def", "gc-sparse.params", 432, 10),
 }
 
 

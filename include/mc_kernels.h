@@ -216,6 +216,25 @@ int mc_eltwise_max(const float* a, const float* b, float* out, size_t n, mcStrea
 int mc_compute_eltwise_max_grad(const float* actGrad, const float* input, const float* output,
                                 float* target, int add, size_t n, mcStream_t stream);
 
+/* ---------------- random sparse connectivity (randSparse conv / local layers) ----------------
+ * convFilterActsSparse / convImgActsSparse / convWeightActsSparse and the local*Sparse twins
+ * (Kernel/include/conv/cudaconv2.cuh:52-78; filter_acts.cu:2226-2245, img_acts.cu:2058-2079,
+ * weight_acts.cu:1110-1127) connect filter group g to the channels dColorIndices[g*numFilterColors + c].
+ * Here that is three steps, each through this header:
+ *   forward / weight gradient: mc_conv_gather_channels(images, dColorIndices, gathered, ...) and then the dense
+ *     grouped entry point on `gathered` with numImgColors = numGroups*numFilterColors;
+ *   backward data: the dense grouped mc_conv_img_acts into a (numGroups*numFilterColors)-channel temporary, then
+ *     mc_conv_scatter_channels sums, for every real channel c, the `overSample` gathered channels
+ *     inverseIndices[c*overSample + o] that were copies of it (the reference leaves that sum to the layer,
+ *     layer.cu:531-535): target = scaleTargets*target + scaleOutput*sum.
+ * Index arrays are int32 on the device; an index outside the source tensor contributes zeros. */
+int mc_conv_gather_channels(const float* images, const int* channelIndices, float* target,
+                            int numImages, int numImgColors, int numIndices, int imgPixels,
+                            mcStream_t stream);
+int mc_conv_scatter_channels(const float* gathered, const int* inverseIndices, float* target,
+                             int numImages, int numImgColors, int overSample, int imgPixels,
+                             float scaleTargets, float scaleOutput, mcStream_t stream);
+
 /* ---------------- group sparsity over same-label cases (plugin cost.gsinlabel) ----------------
  * CalculateSqrtSumSquareMatrix / CalculateGradient (PluginsSrc/src/extrautils.cu:128-158, 201-211).
  * acts is (channels*imagePixels, numCases), labels (1, numCases).  For every channel and every distinct label

@@ -441,3 +441,24 @@ def group_sparsity_in_label_grad(labels, acts, channels, coeff, target=None, sca
     if scale_targets != 0:
         out = scale_targets * target.astype(np.float64) + out
     return out.astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# random sparse connectivity (randSparse conv / local layers)
+# --------------------------------------------------------------------------
+def gather_channels(imgs, conns, C, N):
+    """The channel indirection of the *Sparse kernels (Kernel/src/conv/filter_acts.cu:259-413: filter group g reads
+    channel colorIndices[g*numFilterColors + c]) as a tensor: out channel k = input channel conns[k]."""
+    x = imgs.reshape(C, -1, N)
+    return _f32(x[np.asarray(conns, np.int64)].reshape(-1, N))
+
+
+def scatter_channels(gathered, conns, C, N, target=None, scale_targets=0.0, scale_output=1.0):
+    """Backward of gather_channels: every real channel sums the gradients of its copies, in ascending position
+    (convImgActsSparse + the overSample sum of Kernel/src/layers/layer.cu:526-535)."""
+    conns = np.asarray(conns, np.int64)
+    g = gathered.reshape(len(conns), -1, N)
+    out = np.zeros((C, g.shape[1], N), np.float32)
+    for k, c in enumerate(conns):
+        out[c] = out[c] + g[k]
+    return _blend(target, out.reshape(-1, N), scale_targets, scale_output)

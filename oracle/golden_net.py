@@ -68,7 +68,8 @@ class GoldenNet(object):
             elif t in ("conv", "local"):                                   # layer.cu:470-489, 557-570
                 out = None
                 for i, x in enumerate(ins):
-                    geo = (N, l["channels"][i], l["imgSize"][i], l["imgSize"][i], l["filters"], l["filterSize"][i], l["padding"][i],
+                    x, ch = self._conv_input(l, i, x, N)
+                    geo = (N, ch, l["imgSize"][i], l["imgSize"][i], l["filters"], l["filterSize"][i], l["padding"][i],
                            l["stride"][i], l["modulesX"], l["modulesX"], l["groups"][i])
                     out = G.filter_acts(x, self.weight(name, i), *geo, targets=out, scale_targets=0.0 if out is None else 1.0, conv=(t == "conv"))
                 b = self.B[name]
@@ -135,6 +136,14 @@ class GoldenNet(object):
                 raise NotImplementedError("golden net: layer type " + t)
         return self.costs
 
+    @staticmethod
+    def _conv_input(l, i, x, N):
+        """(input tensor, channel count) the dense grouped contraction of input i runs on: for a randSparse input
+        the connected channels gathered group by group (layer.cu:471-474, 509-512, 526-530)."""
+        if l["randSparse"][i]:
+            return G.gather_channels(x, l["filterConns"][i], l["channels"][i], N), l["groups"][i] * l["filterChannels"][i]
+        return x, l["channels"][i]
+
     def cost_value(self):
         """Cost::getValue (Kernel/src/layers/cost.cu:64-70)."""
         return sum(l["coeff"] * self.costs[l["name"]][0] for l in self.layers if l["type"].startswith("cost."))
@@ -190,14 +199,18 @@ class GoldenNet(object):
                     rows = l["filters"] if (conv and l["sharedBiases"]) else l["filters"] * l["modules"]
                     self.bgrads[name] = (s * v.reshape(rows, -1).astype(np.float64).sum(axis=1)).astype(F32).reshape(self.B[name].shape)
                 for i, x in enumerate(ins):
-                    geo = (N, l["channels"][i], l["imgSize"][i], l["imgSize"][i], l["filters"], l["filterSize"][i], l["padding"][i],
+                    x, ch = self._conv_input(l, i, x, N)
+                    geo = (N, ch, l["imgSize"][i], l["imgSize"][i], l["filters"], l["filterSize"][i], l["padding"][i],
                            l["stride"][i], l["modulesX"], l["modulesX"], l["groups"][i])
                     if l["epsW"][i] > 0:                                   # layer.cu:503-523, 578-591
                         s = 1.0 if gc else l["epsW"][i] / Ng
                         dw = G.weight_acts(x, v, *geo, partial_sum=0, scale_output=s, conv=conv)
                         key = self._owner((name, i))
                         self.wgrads[key] = dw if key not in self.wgrads else (self.wgrads[key] + dw).astype(F32)
-                    send(inp[i], G.img_acts(v, self.weight(name, i), *geo, conv=conv))      # layer.cu:525-540, 593-602
+                    dx = G.img_acts(v, self.weight(name, i), *geo, conv=conv)               # layer.cu:525-540, 593-602
+                    if l["randSparse"][i]:
+                        dx = G.scatter_channels(dx, l["filterConns"][i], l["channels"][i], N)
+                    send(inp[i], dx)
             elif t == "fc":                                                # layer.cu:380-409
                 if l["epsB"] > 0:
                     s = 1.0 if gc else l["epsB"] / Ng

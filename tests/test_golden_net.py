@@ -33,7 +33,7 @@ def _numeric_vs_analytic(net, data, tensor, step, picks, rng):
     return np.linalg.norm(num - ana) / max(np.linalg.norm(ana), 1e-30)
 
 
-@pytest.mark.parametrize("name", ["gc-small", "nin-tiny", "image-layers"])
+@pytest.mark.parametrize("name", ["gc-small", "nin-tiny", "image-layers", "gc-sparse"])
 def test_finite_differences(name):
     layers, dims, classes = modelutil.load_net(name, seed=7)
     data = modelutil.synthetic_batch(dims, classes, 8)

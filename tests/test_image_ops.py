@@ -148,3 +148,33 @@ def test_group_sparsity_in_label_cost_and_its_gradient():
         dn[idx] -= h
         num = (cost_by_definition(up) - cost_by_definition(dn)) / (up[idx].astype(np.float64) - dn[idx])
         assert abs(-g[idx] - num) < 1e-3 * max(1.0, abs(num)), (idx, g[idx], num)
+
+
+def test_sparse_connectivity_equals_dense_conv_with_zero_embedded_filters():
+    """randSparse (Kernel/src/conv/filter_acts.cu:259-413): group g's filters see channels conns[g*fc + c].  The
+    oracle's route -- gather the channels, then the dense grouped contraction -- must equal an ordinary dense
+    convolution whose filters are zero on every unconnected channel; its backward passes must be the adjoints."""
+    rng = np.random.default_rng(7)
+    N, C, S, fs, pad, stride, groups, fc, fpg = 4, 6, 7, 3, 1, 1, 3, 4, 2      # overSample = 3*4/6 = 2
+    F = groups * fpg
+    M = 1 + int(np.ceil((2 * pad + S - fs) / float(stride)))
+    conns = [int(x) for _ in range(groups * fc // C) for x in rng.permutation(C)]
+    x = rng.standard_normal((C * S * S, N)).astype(np.float32)
+    W = rng.standard_normal((fc * fs * fs, F)).astype(np.float32)
+    xg = G.gather_channels(x, conns, C, N)
+    sparse = G.filter_acts(xg, W, N, groups * fc, S, S, F, fs, -pad, stride, M, M, groups)
+    Wfull = np.zeros((C, fs * fs, F), np.float32)
+    for g in range(groups):
+        for c in range(fc):
+            Wfull[conns[g * fc + c], :, g * fpg:(g + 1) * fpg] += W.reshape(fc, fs * fs, F)[c, :, g * fpg:(g + 1) * fpg]
+    dense = G.filter_acts(x, Wfull.reshape(C * fs * fs, F), N, C, S, S, F, fs, -pad, stride, M, M, 1)
+    np.testing.assert_allclose(sparse, dense, rtol=1e-5, atol=1e-5)
+    # backward data: gradient of the gathered tensor scattered back == dense backward with the embedded filters
+    gout = rng.standard_normal(sparse.shape).astype(np.float32)
+    dxg = G.img_acts(gout, W, N, groups * fc, S, S, F, fs, -pad, stride, M, M, groups)
+    dx = G.scatter_channels(dxg, conns, C, N)
+    dx_dense = G.img_acts(gout, Wfull.reshape(C * fs * fs, F), N, C, S, S, F, fs, -pad, stride, M, M, 1)
+    np.testing.assert_allclose(dx, dx_dense, rtol=1e-5, atol=1e-5)
+    # accumulate form of the scatter
+    prev = rng.standard_normal(x.shape).astype(np.float32)
+    np.testing.assert_allclose(G.scatter_channels(dxg, conns, C, N, target=prev, scale_targets=1.0), prev + dx, rtol=1e-6, atol=1e-6)

@@ -160,3 +160,35 @@ def test_group_sparsity_in_label_cost_and_grad(N, ch, P, classes):
         t = nans(*acts.shape) if sT == 0 else dev(prev)
         m.call("mc_group_sparsity_in_label_grad", ptr(da), ptr(sq), ptr(cnt), ptr(t), N, ch, P, sT, -0.5, None)
         close(host(t), G.group_sparsity_in_label_grad(labels, acts, ch, 0.5, target=prev, scale_targets=sT), 1e-5)
+
+
+@pytest.mark.parametrize("N,C,P,groups,fc", [(128, 8, 64, 4, 4), (16, 6, 49, 3, 4), (5, 16, 9, 2, 8), (6, 3, 4, 1, 3)])
+def test_channel_gather_and_scatter(N, C, P, groups, fc):
+    """randSparse plumbing: gather of the connected channels and the per-channel sum of their gradients, bit for bit."""
+    import torch
+    m = mc()
+    rng = np.random.default_rng(37)
+    K = groups * fc
+    O = K // C
+    conns = np.array([int(x) for _ in range(O) for x in rng.permutation(C)], np.int32)
+    inv = np.full((C, O), -1, np.int32)
+    seen = np.zeros(C, np.int64)
+    for k, c in enumerate(conns):
+        inv[c, seen[c]] = k
+        seen[c] += 1
+    x = rng.standard_normal((C * P, N)).astype(np.float32)
+    dx = dev(x)
+    dconns = torch.from_numpy(conns).cuda()
+    dinv = torch.from_numpy(inv.reshape(-1)).cuda()
+    y = nans(K * P, N)
+    m.call("mc_conv_gather_channels", ptr(dx), dconns.data_ptr(), ptr(y), N, C, K, P, None)
+    assert np.array_equal(host(y), G.gather_channels(x, conns, C, N))
+    g = rng.standard_normal((K * P, N)).astype(np.float32)
+    dg = dev(g)
+    t = nans(C * P, N)
+    m.call("mc_conv_scatter_channels", ptr(dg), dinv.data_ptr(), ptr(t), N, C, O, P, 0.0, 1.0, None)
+    assert np.array_equal(host(t), G.scatter_channels(g, conns, C, N))
+    prev = rng.standard_normal(x.shape).astype(np.float32)
+    t2 = dev(prev)
+    m.call("mc_conv_scatter_channels", ptr(dg), dinv.data_ptr(), ptr(t2), N, C, O, P, 1.0, 1.0, None)
+    np.testing.assert_allclose(host(t2), G.scatter_channels(g, conns, C, N, target=prev, scale_targets=1.0), rtol=1e-6, atol=1e-6)

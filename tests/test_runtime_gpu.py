@@ -68,7 +68,9 @@ def rel_l2(got, exp):
 CASES = [("gc-small", 128 + 70, 128, "max"), ("nin-tiny", 128 + 70, 128, "max"), ("80sec", 128 + 36, 128, "max"),
          ("18pct", 64, 64, "max"), ("conv-local", 34, 64, "l2"),
          # SURVEY 8f.3 layers: rgb2lab / rgb2yuv / blur / resize in front of two convs joined by eltmax, then blur + nailbed
-         ("image-layers", 64 + 22, 64, "max")]
+         ("image-layers", 64 + 22, 64, "max"),
+         # random sparse connectivity in a conv (groups 4, overSample 2) and a local layer (groups 2)
+         ("gc-sparse", 128 + 70, 128, "max")]
 
 
 @pytest.mark.parametrize("net_name,cases,mini,metric", CASES)
@@ -118,9 +120,11 @@ def test_test_pass_costs_and_no_update():
     assert rel_rms(got["acts:probs"], net.acts["probs"]) < 1e-4     # last (tail) minibatch: 22 cases
 
 
-def test_gradient_check_passes():
-    """The reference's --check-grads on a layers.gc.cfg-style net: every tensor below 2% rel error."""
-    got, out = run_child(net="gc-small", cases=32, mini=32, check_grads=1)
+@pytest.mark.parametrize("net_name", ["gc-small", "gc-sparse"])
+def test_gradient_check_passes(net_name):
+    """The reference's --check-grads on layers.gc.cfg-style nets (dense, and with randSparse layers as the
+    reference's own layers.gc.cfg has): every tensor below 2% rel error."""
+    got, out = run_child(net=net_name, cases=32, mini=32, check_grads=1)
     assert int(got["failures"]) == 0, out[-2000:]
     assert "TESTS PASSED" in out
 
