@@ -13,6 +13,10 @@ CONFIGS = os.path.join(HERE, "configs")
 NETS = {   # name -> (layer-def, layer-params, data dims, classes)
     "nin": ("nin-cifar10.def", "nin-cifar10.params", 3072, 10),
     "nin-tiny": ("nin-tiny.def", "nin-tiny.params", 768, 10),
+    "nin-cifar100": ("nin-cifar100.def", "nin-cifar100.params", 3072, 100),
+    "nin-mnist": ("nin-mnist.def", "nin-mnist.params", 784, 10),
+    "nin-svhn": ("nin-svhn.def", "nin-svhn.params", 3072, 10),
+    "19pct": ("layers-19pct.cfg", "layer-params-19pct.cfg", 3072, 10),
     "80sec": ("layers-80sec.cfg", "layer-params-80sec.cfg", 3072, 10),
     "18pct": ("layers-18pct.cfg", "layer-params-18pct.cfg", 3072, 10),
     "conv-local": ("layers-conv-local-13pct.cfg", "layer-params-conv-local-13pct.cfg", 3072, 10),

@@ -74,7 +74,10 @@ def test_parse_errors_exit(tmp_path, capsys):
 REF_PAIRS = [("nin", "NIN/cifar-10_def", "NIN/cifar-10_params"), ("80sec", "example-layers/layers-80sec.cfg", "example-layers/layer-params-80sec.cfg"),
              ("conv-local", "example-layers/layers-conv-local-13pct.cfg", "example-layers/layer-params-conv-local-13pct.cfg"),
              ("imagenet", "example-layers/imagenet", "example-layers/imagenet_params"),
-             ("18pct", "example-layers/layers-18pct.cfg", "example-layers/layer-params-18pct.cfg")]
+             ("18pct", "example-layers/layers-18pct.cfg", "example-layers/layer-params-18pct.cfg"),
+             ("19pct", "example-layers/layers-19pct.cfg", "example-layers/layer-params-19pct.cfg"),
+             ("nin-cifar100", "NIN/cifar-100_def", "NIN/cifar-100_params"), ("nin-mnist", "NIN/mnist_def", "NIN/mnist_params"),
+             ("nin-svhn", "NIN/svhn_def", "NIN/svhn_params")]
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")

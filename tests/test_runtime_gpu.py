@@ -70,7 +70,11 @@ CASES = [("gc-small", 128 + 70, 128, "max"), ("nin-tiny", 128 + 70, 128, "max"),
          # SURVEY 8f.3 layers: rgb2lab / rgb2yuv / blur / resize in front of two convs joined by eltmax, then blur + nailbed
          ("image-layers", 64 + 22, 64, "max"),
          # random sparse connectivity in a conv (groups 4, overSample 2) and a local layer (groups 2)
-         ("gc-sparse", 128 + 70, 128, "max")]
+         ("gc-sparse", 128 + 70, 128, "max"),
+         # the remaining config pairs the reference ships (NIN cifar-100 / mnist / svhn, layers-19pct), full size, small batches.
+         # cifar-100 starts from initW = 0.001 and the mnist net sees a 1-channel U[0,1) image: both have near-tied max-pool
+         # windows like conv-local above (bias gradients, sums with heavy cancellation, move by 2e-3 of their RMS) -> Frobenius norm
+         ("nin-cifar100", 16 + 6, 16, "l2"), ("nin-mnist", 32 + 6, 32, "l2"), ("nin-svhn", 16 + 6, 16, "max"), ("19pct", 64 + 6, 64, "max")]
 
 
 @pytest.mark.parametrize("net_name,cases,mini,metric", CASES)
