@@ -22,6 +22,14 @@ def make_masks(layers, cases, mini, seed=99):
     return out
 
 
+def multiview_batch(dims, classes, cases, views):
+    """`views` different synthetic views of `cases` images, view-major as the cropped provider lays them
+    out (convdata.py:68-80), every view carrying the same labels."""
+    data = modelutil.synthetic_batch(dims, classes, cases * views)
+    data[1] = np.ascontiguousarray(np.tile(data[1][:, :cases], (1, views)))
+    return data
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--net", required=True)
@@ -32,18 +40,33 @@ def main():
     ap.add_argument("--single-rank-comm", type=int, default=0)
     ap.add_argument("--check-grads", type=int, default=0)
     ap.add_argument("--acts", default="")
+    ap.add_argument("--multiview", type=int, default=0, help="number of views: startMultiviewTest on cases*views columns")
+    ap.add_argument("--features", default="", help="layer name: startFeatureWriter into a (cases, outputs) matrix")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
 
     import libkernel
     layers, dims, classes = modelutil.load_net(a.net, seed=a.seed)
-    data = modelutil.synthetic_batch(dims, classes, a.cases)
+    data = multiview_batch(dims, classes, a.cases, a.multiview) if a.multiview else modelutil.synthetic_batch(dims, classes, a.cases)
     libkernel.initModel(layers, a.mini, 0)
     if a.single_rank_comm:
         libkernel.initComm(0, 1, libkernel.commUniqueId(), 1)
     if a.check_grads:
         failures = libkernel.checkGradients(data)
         np.savez(a.out, failures=failures)
+        return
+    if a.multiview:
+        logreg = [i for i, l in enumerate(layers) if l["type"] == "cost.logreg"][0]
+        libkernel.startMultiviewTest(data, a.multiview, logreg)
+        costs, ncases = libkernel.finishBatch()
+        np.savez(a.out, numCases=ncases, **{"cost:" + k: np.array(v) for k, v in costs.items()})
+        return
+    if a.features:
+        idx = [i for i, l in enumerate(layers) if l["name"] == a.features][0]
+        ftrs = np.full((a.cases, layers[idx]["outputs"]), np.nan, dtype=np.float32)
+        libkernel.startFeatureWriter(data + [ftrs], idx)
+        costs, ncases = libkernel.finishBatch()
+        np.savez(a.out, numCases=ncases, ftrs=ftrs, **{"cost:" + k: np.array(v) for k, v in costs.items()})
         return
     if not a.test:
         libkernel.setDropoutMasks([m for mb in make_masks(layers, a.cases, a.mini) for m in mb])

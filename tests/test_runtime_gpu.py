@@ -146,6 +146,49 @@ def test_image_layers_forward_matches_oracle():
     np.testing.assert_allclose(got["cost:logprob"], costs["logprob"], rtol=2e-4, atol=1e-3)
 
 
+def test_multiview_test_matches_oracle():
+    """startMultiviewTest (worker.cu:142-174): class probabilities averaged over the views of each case, then the
+    logreg cost of the average.  3 views of 150 cases, minibatch 64 (two full real minibatches and a 22-case tail)."""
+    sys.path.insert(0, HERE)
+    from run_net_step import multiview_batch
+    from oracle import golden
+    cases, views, mini = 150, 3, 64
+    got, _ = run_child(net="nin-tiny", cases=cases, mini=mini, multiview=views)
+    layers, dims, classes = modelutil.load_net("nin-tiny", seed=42)
+    data = multiview_batch(dims, classes, cases, views)
+    net = GoldenNet(layers)
+    exp = np.zeros(2)
+    for s in range(0, cases, mini):
+        e = min(cases, s + mini)
+        probs = 0
+        for v in range(views):
+            net.fprop([d[:, v * cases + s:v * cases + e] for d in data], train=False)
+            probs = probs + net.acts["probs"]
+        probs = (probs * np.float32(1.0 / views)).astype(np.float32)
+        exp += np.array(golden.logreg_cost(data[1][:, s:e], probs))
+    assert int(got["numCases"]) == cases
+    np.testing.assert_allclose(got["cost:logprob"][0], exp[0], rtol=2e-4)
+    assert abs(got["cost:logprob"][1] - exp[1]) <= 1.0
+
+
+def test_feature_writer_matches_oracle():
+    """startFeatureWriter (worker.cu:191-214): the chosen layer's test-mode activations, transposed to
+    (cases, outputs) C order and written into the caller's matrix, minibatch by minibatch (ragged tail)."""
+    cases, mini = 150, 64
+    got, _ = run_child(net="nin-tiny", cases=cases, mini=mini, features="pool2")
+    layers, dims, classes = modelutil.load_net("nin-tiny", seed=42)
+    data = modelutil.synthetic_batch(dims, classes, cases)
+    net = GoldenNet(layers)
+    rows = []
+    for s in range(0, cases, mini):
+        net.fprop([d[:, s:s + mini] for d in data], train=False)
+        rows.append(net.acts["pool2"].T.copy())
+    exp = np.concatenate(rows, axis=0)
+    assert got["ftrs"].shape == exp.shape and not np.isnan(got["ftrs"]).any()
+    assert rel_rms(got["ftrs"], exp) < 1e-4
+    assert int(got["numCases"]) == cases
+
+
 def test_single_rank_rccl_path_is_identity():
     """world_size 1 through the real RCCL all-reduce / side-stream / event path gives the same
     weights as the path without a communicator."""
