@@ -28,19 +28,17 @@ def pickle(filename, data, compress=False):
 
 
 def unpickle(filename):
-    """Loads a checkpoint / data batch.  Python-2 cPickle files (the reference's own format) need
-    encoding='latin1' for their NumPy payloads."""
+    """Loads a checkpoint / data batch.  Python-2 cPickle files (the reference's own format) carry their
+    NumPy payloads as 8-bit `str`: encoding='latin1' maps those bytes one to one (the default 'ASCII'
+    raises on the first byte above 127, or silently mangles a payload that happens to be all-ASCII);
+    the argument has no effect on files Python 3 wrote."""
     if not os.path.exists(filename):
         raise UnpickleError("Path '%s' does not exist." % filename)
     with open(filename, "rb") as fo:
         magic = fo.read(2)
     opener = gzip.open if magic == b"\x1f\x8b" else open
     with opener(filename, "rb") as fo:
-        try:
-            return _pickle.load(fo)
-        except UnicodeDecodeError:
-            fo.seek(0)
-            return _pickle.load(fo, encoding="latin1")
+        return _pickle.load(fo, encoding="latin1")
 
 
 def is_windows_machine():

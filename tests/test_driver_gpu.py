@@ -50,3 +50,24 @@ def test_check_grads_flag():
                    "--layer-params=" + os.path.join(modelutil.CONFIGS, "gc-small.params"), "--data-provider=dummy-cn-432", "--mini=32"])
     assert rc == 0, out[-3000:]
     assert re.search(r"ALL \d+ TESTS PASSED", out), out[-3000:]
+
+
+def test_resume_with_conv_to_local(tmp_path):
+    """-f <checkpoint> --conv-to-local=conv2 (convnet.py:78-84 of the reference): the resumed run converts the
+    layer, keeps training through the unshared kernels, and the next checkpoint holds the per-module filter bank."""
+    cfg = ["--layer-def=" + os.path.join(modelutil.CONFIGS, "layers-80sec.cfg"), "--layer-params=" + os.path.join(modelutil.CONFIGS, "layer-params-80sec.cfg")]
+    base = ["--data-path=" + str(tmp_path), "--save-path=" + str(tmp_path), "--train-range=1", "--test-range=1", "--data-provider=dummy-cn-3072", "--test-freq=1"]
+    rc, out = run(base + cfg + ["--epochs=1"])
+    assert rc == 0, out[-3000:]
+    ckpt = tmp_path / [d for d in os.listdir(tmp_path) if d.startswith("ConvNet__")][0]
+    rc, out = run(["-f", str(ckpt), "--conv-to-local=conv2", "--epochs=3"])
+    assert rc == 0, out[-3000:]
+    assert "Converted layer 'conv2' from convolutional to unshared, locally-connected" in out
+    lines = re.findall(r"^([23])\.1\.\.\. logprob:  ([\d.]+)", out, flags=re.M)
+    assert lines and all(0.5 < float(v) < 5 for _, v in lines), out[-3000:]
+    with open(ckpt / sorted(os.listdir(ckpt), key=lambda s: [int(x) for x in s.split(".")])[-1], "rb") as f:
+        dic = pickle.load(f)
+    conv2 = [l for l in dic["model_state"]["layers"] if l["name"] == "conv2"][0]
+    assert conv2["type"] == "local" and conv2["weights"][0].shape == (conv2["modules"] * 32 * 25, 32)
+    bank = conv2["weights"][0].reshape(conv2["modules"], -1, 32)
+    assert abs(bank[0] - bank[conv2["modules"] // 2]).max() > 0           # the modules have trained apart

@@ -108,3 +108,77 @@ def test_reference_gc_config_parses():
     by = dict((l["name"], l) for l in layers)
     assert by["local32"]["randSparse"] == [True] and len(by["local32"]["filterConns"][0]) == by["local32"]["groups"][0] * by["local32"]["filterChannels"][0]
     assert by["avgpool"]["start"] == -2 and by["fc10"]["inputs"] == [6, 3] or by["fc10"]["numInputs"] == [by["local32"]["outputs"], by["conv32"]["outputs"]]
+
+
+def test_conv_to_local_is_the_same_function():
+    """--conv-to-local (layer.py:816-844): the filter bank tiled once per module.  The converted net computes the
+    same forward pass, and after one training step the per-module weight increments of the local layer add up
+    to the shared layer's increment (the shared gradient is the sum over modules, weight_acts.cu:608-681)."""
+    import layer
+    from oracle.golden_net import GoldenNet
+    conv, dims, classes = modelutil.load_net("80sec", seed=11)
+    loc, _, _ = modelutil.load_net("80sec", seed=11)
+    idx = [l["name"] for l in loc].index("conv2")
+    layer.LocalLayerParser.conv_to_local(loc, idx)
+    c, l = conv[idx], loc[idx]
+    assert l["type"] == "local" and l["weights"][0].shape == (c["modules"] * c["weights"][0].shape[0], c["filters"])
+    assert l["biases"].shape == (c["modules"] * c["filters"], 1) and l["weights"][0].flags["C_CONTIGUOUS"]
+    np.testing.assert_array_equal(l["weights"][0].reshape(c["modules"], -1, c["filters"])[7], c["weights"][0])
+    for d in (c, l):
+        d["wc"], d["momW"] = [0.0], [0.0]          # increments = eps * gradient: comparable between the two
+    data = modelutil.synthetic_batch(dims, classes, 16)
+    a, b = GoldenNet(conv), GoldenNet(loc)
+    ca, cb = a.train_step(data), b.train_step(data)
+    np.testing.assert_allclose(ca["logprob"], cb["logprob"], rtol=1e-6)
+    summed = b.Winc[("conv2", 0)].reshape(c["modules"], -1, c["filters"]).astype(np.float64).sum(axis=0)
+    ref = a.Winc[("conv2", 0)]
+    assert np.abs(summed - ref).max() < 1e-4 * np.sqrt((ref.astype(np.float64) ** 2).mean())
+    bsum = b.Binc["conv2"].reshape(c["filters"], c["modules"]).astype(np.float64).sum(axis=1)
+    assert np.abs(bsum - a.Binc["conv2"].reshape(-1)).max() < 1e-4 * np.abs(a.Binc["conv2"]).max()
+
+
+SHARED = """[data]
+type=data
+dataIdx=0
+[labels]
+type=data
+dataIdx=1
+[fca]
+type=fc
+inputs=data
+outputs=12
+initW=0.1
+[fcb]
+type=fc
+inputs=data,fca
+outputs=12
+initW=0.1,0.1
+weightSource=fca,
+[probs]
+type=softmax
+inputs=fcb
+[logprob]
+type=cost.logreg
+inputs=labels,probs
+"""
+SHARED_PARAMS = "".join("[%s]\nepsW=%s\nepsB=0.01\nmomW=%s\nmomB=0\nwc=%s\n" % (nm, v, v0, v0)
+                        for nm, v, v0 in (("fca", "0.01", "0"), ("fcb", "0.01,0.01", "0,0"))) + "[logprob]\ncoeff=1\n"
+
+
+def test_weight_sharing_and_unshare(tmp_path, capsys):
+    """weightSource makes two layers hold the SAME ndarray (layer.py:693-703); --unshare-weights gives the
+    borrower its own copy and clears the source indices (layer.py:653-669)."""
+    import layer
+    (tmp_path / "s.def").write_text(SHARED)
+    (tmp_path / "s.params").write_text(SHARED_PARAMS)
+    layers = modelutil.parse_net(str(tmp_path / "s.def"), str(tmp_path / "s.params"), 20, 12)
+    by = dict((l["name"], l) for l in layers)
+    assert by["fcb"]["weights"][0] is by["fca"]["weights"][0] and by["fcb"]["weightsInc"][0] is by["fca"]["weightsInc"][0]
+    assert by["fcb"]["weightSourceLayerIndices"] == [2, -1] and by["fcb"]["weightSourceMatrixIndices"] == [0, -1]
+    layer.WeightLayerParser.unshare_weights(by["fcb"], layers, matrix_idx=0)
+    assert by["fcb"]["weights"][0] is not by["fca"]["weights"][0]
+    np.testing.assert_array_equal(by["fcb"]["weights"][0], by["fca"]["weights"][0])
+    assert by["fcb"]["weightSourceLayerIndices"] == [-1, -1] and not by["fcb"]["weightsInc"][0].any()
+    layer.WeightLayerParser.unshare_weights(by["fcb"], layers)
+    out = capsys.readouterr().out
+    assert "Unshared weight matrix fcb[0] from fca[0]." in out and "Weight matrix fcb[0] already unshared." in out
