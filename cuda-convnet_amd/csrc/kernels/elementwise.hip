@@ -156,6 +156,40 @@ __global__ void k_rand_uniform(float* out, size_t n, unsigned long long seed, un
     }
 }
 
+// Dropout whose uniforms are never stored: lane v handles elements 4v..4v+3 = one Philox block of the stream
+// k_rand_uniform would write for (seed, offset), so the result equals mc_rand_uniform + mc_dropout_apply bit for bit
+// and the backward pass regenerates the same mask from the same (seed, offset).
+__global__ void k_dropout_counter(const float* in, float* out, float p, bool add, size_t n, unsigned long long seed, unsigned long long offset,
+                                  bool vec4) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t nblk = (n + 3) / 4;
+    for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += stride) {
+        const unsigned long long ctr = offset / 4 + b;
+        unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = (unsigned)(offset & 3), c3 = 0x6d633535u;
+        unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c0, c1, c2, c3, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        const float u[4] = {u01(c0), u01(c1), u01(c2), u01(c3)};
+        if (vec4 && b * 4 + 3 < n) {
+            const float4 x = reinterpret_cast<const float4*>(in)[b];
+            float4 r = make_float4(u[0] < p ? 0.f : x.x, u[1] < p ? 0.f : x.y, u[2] < p ? 0.f : x.z, u[3] < p ? 0.f : x.w);
+            if (add) {
+                const float4 t = reinterpret_cast<float4*>(out)[b];
+                r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+            }
+            reinterpret_cast<float4*>(out)[b] = r;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (b * 4 + e < n) out[b * 4 + e] = (add ? out[b * 4 + e] : 0.f) + (u[e] < p ? 0.f : in[b * 4 + e]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- bias add / reductions
 // acts(rows, cols): acts[r][c] += s*vec[r]
 __global__ void k_add_row_vector(float* acts, const float* __restrict__ vec, int rows, int cols, float s, bool vec4) {
@@ -440,6 +474,17 @@ int mc_dropout_apply(const float* in, const float* mask, float* out, float prob,
     MC_REQUIRE(in && mask && out, "mc_dropout_apply: null pointer");
     MC_REQUIRE(prob > 0.f && prob < 1.f, "mc_dropout_apply: prob must be in (0,1), got %g", (double)prob);
     return map2(in, mask, out, n, add != 0, FDropout{prob}, S(s));
+}
+
+int mc_dropout_counter(const float* in, float* out, float prob, int add, size_t n, unsigned long long seed, unsigned long long offset,
+                       mcStream_t s) {
+    MC_REQUIRE(in && out, "mc_dropout_counter: null pointer");
+    MC_REQUIRE(prob > 0.f && prob < 1.f, "mc_dropout_counter: prob must be in (0,1), got %g", (double)prob);
+    MC_REQUIRE(offset % 4 == 0, "mc_dropout_counter: offset must be a multiple of 4");
+    if (n == 0) return MC_OK;
+    hipLaunchKernelGGL(k_dropout_counter, dim3(grid_for((n + 3) / 4)), dim3(TPB), 0, S(s), in, out, prob, add != 0, n, seed, offset,
+                       aligned16(in) && aligned16(out));
+    return launch_status("mc_dropout_counter");
 }
 
 int mc_rand_uniform(float* out, size_t n, unsigned long long seed, unsigned long long offset, mcStream_t s) {

@@ -103,9 +103,16 @@ public:
         _outputs = &outputs;
         if (&inputs != &outputs) outputs.resize(inputs);
         if (passType == PASS_TRAIN) {
-            _mask.resize(inputs);
-            fillUniform(_mask);
-            RT_MC(mc_dropout_apply(inputs.data(), _mask.data(), outputs.data(), _prob, 0, inputs.numel(), ST()));
+            // the uniforms are a counter-based stream: forward and backward regenerate them from (seed, offset)
+            // instead of writing and re-reading a mask matrix; an injected mask (tests) takes the stored path
+            _counter = reserveUniform(inputs.numel(), &_seed, &_offset);
+            if (_counter) {
+                RT_MC(mc_dropout_counter(inputs.data(), outputs.data(), _prob, 0, inputs.numel(), _seed, _offset, ST()));
+            } else {
+                _mask.resize(inputs);
+                fillUniform(_mask);
+                RT_MC(mc_dropout_apply(inputs.data(), _mask.data(), outputs.data(), _prob, 0, inputs.numel(), ST()));
+            }
         } else {
             RT_MC(mc_scale(outputs.data(), inputs.data(), 1.f - _prob, inputs.numel(), ST()));
         }
@@ -113,7 +120,9 @@ public:
 
     void computeInputGrad(DevMat& actsGrad, DevMat& target, bool add, PASS_TYPE passType) override {
         if (!add && &target != &actsGrad) target.resize(actsGrad);
-        if (passType == PASS_TRAIN) {
+        if (passType == PASS_TRAIN && _counter) {
+            RT_MC(mc_dropout_counter(actsGrad.data(), target.data(), _prob, add ? 1 : 0, actsGrad.numel(), _seed, _offset, ST()));
+        } else if (passType == PASS_TRAIN) {
             RT_MC(mc_dropout_apply(actsGrad.data(), _mask.data(), target.data(), _prob, add ? 1 : 0, actsGrad.numel(), ST()));
         } else if (add) {
             RT_MC(mc_axpby(target.data(), actsGrad.data(), 1.f, 1.f - _prob, actsGrad.numel(), ST()));
@@ -125,6 +134,8 @@ public:
 private:
     DevMat _mask;
     float _prob;
+    bool _counter = false;
+    unsigned long long _seed = 0, _offset = 0;
 };
 
 // Group sparsity in the label domain: inputs (labels, acts); for every channel and every distinct label of the

@@ -56,9 +56,22 @@ void fillUniform(DevMat& m) {
         g_seeded = true;
     }
     const unsigned long long off = g_offset;
-    g_offset += m.numel();
+    g_offset += (m.numel() + 3) & ~(size_t)3;   // stream positions stay multiples of 4 (one Philox block)
     g.unlock();
     RT_MC(mc_rand_uniform(m.data(), m.numel(), g_seed, off, ST()));
+}
+
+bool reserveUniform(size_t n, unsigned long long* seed, unsigned long long* offset) {
+    std::lock_guard<std::mutex> g(g_randMutex);
+    if (!g_injected.empty()) return false;
+    if (!g_seeded) {
+        g_seed = (unsigned long long)time(nullptr);
+        g_seeded = true;
+    }
+    *seed = g_seed;
+    *offset = g_offset;
+    g_offset += (n + 3) & ~(size_t)3;
+    return true;
 }
 
 // ==========================================================================================

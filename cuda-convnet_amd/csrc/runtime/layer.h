@@ -497,6 +497,10 @@ protected:
 // explicit masks, which are consumed first, in fprop order.
 // ------------------------------------------------------------------------------------------
 void fillUniform(DevMat& m);
+// The same stream without the matrix: reserves n positions and returns where they start, for kernels that
+// generate the uniforms themselves (mc_dropout_counter).  False when an injected mask is pending: the caller
+// must then take the fillUniform path, which consumes it.
+bool reserveUniform(size_t n, unsigned long long* seed, unsigned long long* offset);
 void injectUniform(const float* host, size_t n);
 void setRandSeed(unsigned long long seed);
 

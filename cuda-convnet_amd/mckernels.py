@@ -56,6 +56,7 @@ _SIGS = {
     "mc_neuron_input_grad": [c_i, c_f, c_f, c_fp, c_fp, c_fp, c_i, c_sz, c_fp],
     "mc_dropout_apply": [c_fp, c_fp, c_fp, c_f, c_i, c_sz, c_fp],
     "mc_rand_uniform": [c_fp, c_sz, c_u64, c_u64, c_fp],
+    "mc_dropout_counter": [c_fp, c_fp, c_f, c_i, c_sz, c_u64, c_u64, c_fp],
     "mc_add_row_vector": [c_fp, c_fp, c_i, c_i, c_f, c_fp],
     "mc_sum_rows": [c_fp, c_fp, c_i, c_i, c_f, c_f, c_fp],
     "mc_sum_cols": [c_fp, c_fp, c_i, c_i, c_f, c_f, c_fp],

@@ -273,6 +273,12 @@ int mc_dropout_apply(const float* in, const float* mask, float* out, float prob,
                      mcStream_t stream);
 int mc_rand_uniform(float* out, size_t n, unsigned long long seed, unsigned long long offset,
                     mcStream_t stream);
+/* The two calls above in one, with the uniforms never stored: out = u_i < prob ? 0 : in_i (+ out when `add`) where
+ * u_i is element (offset + i) of mc_rand_uniform's stream for `seed` -- bit-identical to mc_rand_uniform +
+ * mc_dropout_apply.  The backward pass passes the same (seed, offset) and regenerates the mask instead of
+ * reading it (DropoutNeuron keeps a mask matrix in the reference, extralayers.cuh:60-77). */
+int mc_dropout_counter(const float* in, float* out, float prob, int add, size_t n,
+                       unsigned long long seed, unsigned long long offset, mcStream_t stream);
 
 /* ---------------- generic NVMatrix-style ops ----------------
  * Replace the NVMatrix element-wise / vector / aggregation kernels on the path

@@ -279,6 +279,31 @@ def test_dropout_and_rng():
     assert np.array_equal(host(y), G.neuron_fwd("dropout", {"prob": 0.5}, x, train=True, mask=hu))
 
 
+@pytest.mark.parametrize("n", [128 * 96 * 16 * 16, 70 * 192 * 64, 1001])
+def test_dropout_counter_equals_stored_mask(n):
+    """mc_dropout_counter regenerates the uniforms of mc_rand_uniform's stream in the kernel: forward, backward and the
+    accumulate form equal mc_rand_uniform + mc_dropout_apply bit for bit (incl. a tail that is not a multiple of 4)."""
+    m = mc()
+    rng = np.random.default_rng(20)
+    x, g, prev = (dev(rng.standard_normal(n)) for _ in range(3))
+    seed, off = 1234567, 4 * 99991
+    u = zeros(n)
+    m.call("mc_rand_uniform", ptr(u), n, seed, off, None)
+    for src, add in ((x, 0), (g, 0), (g, 1)):
+        a, b = (prev.clone(), prev.clone()) if add else (nans(n), nans(n))
+        m.call("mc_dropout_apply", ptr(src), ptr(u), ptr(a), 0.5, add, n, None)
+        m.call("mc_dropout_counter", ptr(src), ptr(b), 0.5, add, n, seed, off, None)
+        assert np.array_equal(host(a), host(b))
+    # in place, as a neuron layer with actsTarget >= 0 runs it
+    c = x.clone()
+    m.call("mc_dropout_counter", ptr(c), ptr(c), 0.5, 0, n, seed, off, None)
+    e = nans(n)
+    m.call("mc_dropout_apply", ptr(x), ptr(u), ptr(e), 0.5, 0, n, None)
+    assert np.array_equal(host(c), host(e))
+    kept = float((host(c) != 0).mean())
+    assert abs(kept - 0.5) < 0.05
+
+
 def test_bias_and_reductions():
     m = mc()
     rng = np.random.default_rng(20)

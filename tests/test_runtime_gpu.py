@@ -189,6 +189,19 @@ def test_feature_writer_matches_oracle():
     assert int(got["numCases"]) == cases
 
 
+def test_counter_dropout_equals_stored_masks():
+    """Without injected masks the dropout neuron regenerates its uniforms in the forward and backward kernels
+    (mc_dropout_counter) instead of storing a mask: the trained weights equal, bit for bit, a run that is fed the
+    same stream as stored masks (mc_rand_uniform at the same seed and offsets -> mc_dropout_apply)."""
+    a, _ = run_child(net="nin-tiny", cases=128 + 70, mini=128, philox_seed=4321)
+    b, _ = run_child(net="nin-tiny", cases=128 + 70, mini=128, inject_philox=4321)
+    c, _ = run_child(net="nin-tiny", cases=128 + 70, mini=128, philox_seed=4322)
+    for k in a:
+        if k.startswith(("W:", "B:", "Winc:", "Binc:", "cost:")):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert not np.array_equal(a["W:conv2:0"], c["W:conv2:0"])        # another seed is another mask
+
+
 def test_single_rank_rccl_path_is_identity():
     """world_size 1 through the real RCCL all-reduce / side-stream / event path gives the same
     weights as the path without a communicator."""
