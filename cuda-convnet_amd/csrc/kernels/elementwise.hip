@@ -382,6 +382,45 @@ __global__ void k_logreg_cost(const float* __restrict__ labels, const float* __r
         correctProbs[n] = 1.0f / (float)numMax;
     }
 }
+// k_logreg_cost followed by the two sums of LogregCostLayer::fpropActs (layer.cu:993-1005) in one workgroup: lane t takes
+// cases t, t + RED_T, ... and adds them in that order, then the same tree as k_sum_all -- the sums equal
+// mc_compute_logreg_cost + 2 x mc_sum_all bit for bit, without the two dependent launches.
+__global__ void __launch_bounds__(RED_T) k_logreg_cost_sums(const float* __restrict__ labels, const float* __restrict__ probs,
+                                                            float* labelLogProbs, float* correctProbs, double* sums, int numCases, int numOut) {
+    __shared__ double shl[RED_T], shc[RED_T];
+    double accL = 0.0, accC = 0.0;
+    for (int n = threadIdx.x; n < numCases; n += RED_T) {
+        const int label = (int)labels[n];
+        float maxp = probs[n];
+        for (int j = 1; j < numOut; ++j) maxp = fmaxf(maxp, probs[(size_t)j * numCases + n]);
+        const float lp = probs[(size_t)label * numCases + n];
+        const float ll = logf(lp);
+        float cp = 0.f;
+        if (lp == maxp) {
+            int numMax = 0;
+            for (int j = 0; j < numOut; ++j) numMax += probs[(size_t)j * numCases + n] == maxp;
+            cp = 1.0f / (float)numMax;
+        }
+        labelLogProbs[n] = ll;
+        correctProbs[n] = cp;
+        accL += (double)ll;
+        accC += (double)cp;
+    }
+    shl[threadIdx.x] = accL;
+    shc[threadIdx.x] = accC;
+    __syncthreads();
+    for (int s = RED_T / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            shl[threadIdx.x] += shl[threadIdx.x + s];
+            shc[threadIdx.x] += shc[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sums[0] = shl[0];
+        sums[1] = shc[0];
+    }
+}
 // kLogregCostGrad (layer_kernels.cu:84-101): dE/dy_j = coeff * (label == j) / y_j
 __global__ void k_logreg_grad(const float* __restrict__ labels, const float* __restrict__ probs, float* target, bool add,
                               float coeff, int numCases, int numOut) {
@@ -602,6 +641,13 @@ int mc_compute_logreg_cost(const float* labels, const float* probs, float* label
     hipLaunchKernelGGL(k_logreg_cost, dim3(ceil_div(numCases, 64)), dim3(64), 0, S(s), labels, probs, labelLogProbs,
                        correctProbs, numCases, numOut);
     return launch_status("mc_compute_logreg_cost");
+}
+
+int mc_compute_logreg_cost_sums(const float* labels, const float* probs, float* labelLogProbs, float* correctProbs, double* sums,
+                                int numCases, int numOut, mcStream_t s) {
+    MC_REQUIRE(labels && probs && labelLogProbs && correctProbs && sums && numCases > 0 && numOut > 0, "mc_compute_logreg_cost_sums: bad arguments");
+    hipLaunchKernelGGL(k_logreg_cost_sums, dim3(1), dim3(RED_T), 0, S(s), labels, probs, labelLogProbs, correctProbs, sums, numCases, numOut);
+    return launch_status("mc_compute_logreg_cost_sums");
 }
 
 int mc_compute_logreg_grad(const float* labels, const float* probs, float* target, int add, float coeff, int numCases,

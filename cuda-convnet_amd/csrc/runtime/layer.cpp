@@ -931,10 +931,8 @@ void LogregCostLayer::fpropActs(int inpIdx, float, PASS_TYPE) {
     const int N = labels.cols();
     _ownOutputs.resize(1, N);       // log p(label) per case
     _correctProbs.resize(1, N);
-    RT_MC(mc_compute_logreg_cost(labels.data(), probs.data(), _ownOutputs.data(), _correctProbs.data(), N, probs.rows(), ST()));
-    double* slot = costSlot();
-    RT_MC(mc_sum_all(_ownOutputs.data(), N, slot, ST()));
-    RT_MC(mc_sum_all(_correctProbs.data(), N, slot + 1, ST()));
+    // per-case values and both of their sums (this minibatch's cost slot) in one launch
+    RT_MC(mc_compute_logreg_cost_sums(labels.data(), probs.data(), _ownOutputs.data(), _correctProbs.data(), costSlot(), N, probs.rows(), ST()));
 }
 
 void LogregCostLayer::finishCost(double* vals, int numCases) const {

@@ -65,6 +65,7 @@ _SIGS = {
     "mc_sum_all": [c_fp, c_sz, c_fp, c_fp],
     "mc_softmax": [c_fp, c_fp, c_i, c_i, c_fp],
     "mc_compute_logreg_cost": [c_fp] * 4 + [c_i, c_i, c_fp],
+    "mc_compute_logreg_cost_sums": [c_fp] * 5 + [c_i, c_i, c_fp],
     "mc_compute_logreg_grad": [c_fp] * 3 + [c_i, c_f, c_i, c_i, c_fp],
     "mc_compute_softmax_grad": [c_fp] * 3 + [c_i, c_i, c_i, c_fp],
     "mc_compute_logreg_softmax_grad": [c_fp] * 3 + [c_i, c_f, c_i, c_i, c_fp],

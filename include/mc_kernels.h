@@ -309,6 +309,12 @@ int mc_sum_all(const float* v, size_t n, double* out, mcStream_t stream);
 int mc_softmax(const float* input, float* target, int numCases, int numOut, mcStream_t stream);
 int mc_compute_logreg_cost(const float* labels, const float* probs, float* labelLogProbs,
                            float* correctProbs, int numCases, int numOut, mcStream_t stream);
+/* mc_compute_logreg_cost and the two sums LogregCostLayer::fpropActs takes of its outputs (layer.cu:993-1005,
+ * labelLogProbs.sum() and correctProbs.sum(), each a reduction launch + a D->H sync there) in one launch:
+ * sums[0] = sum labelLogProbs, sums[1] = sum correctProbs, in double, same order as mc_sum_all. */
+int mc_compute_logreg_cost_sums(const float* labels, const float* probs, float* labelLogProbs,
+                                float* correctProbs, double* sums, int numCases, int numOut,
+                                mcStream_t stream);
 int mc_compute_logreg_grad(const float* labels, const float* probs, float* target, int add,
                            float coeff, int numCases, int numOut, mcStream_t stream);
 int mc_compute_softmax_grad(const float* acts, const float* actsGrad, float* target, int add,

@@ -328,7 +328,7 @@ def test_bias_and_reductions():
     assert abs(out.item() - v.astype(np.float64).sum()) < 1e-9
 
 
-@pytest.mark.parametrize("N,K", [(128, 10), (16, 10), (128, 100), (5, 7)])
+@pytest.mark.parametrize("N,K", [(128, 10), (16, 10), (128, 100), (5, 7), (2500, 10)])
 def test_softmax_logreg(N, K):
     m = mc()
     rng = np.random.default_rng(21)
@@ -345,6 +345,15 @@ def test_softmax_logreg(N, K):
     ec = G.logreg_cost(labels, hp)
     assert abs(-host(lp).astype(np.float64).sum() - ec[0]) < 1e-4 * max(1.0, abs(ec[0]))
     assert abs((N - host(cp).astype(np.float64).sum()) - ec[1]) < 1e-6
+    # the fused form (values + both sums in one launch) equals the three separate calls bit for bit
+    import torch
+    lp2, cp2 = nans(N), nans(N)
+    sums = torch.full((2,), float("nan"), dtype=torch.float64, device="cuda")
+    sep = torch.full((2,), float("nan"), dtype=torch.float64, device="cuda")
+    m.call("mc_compute_logreg_cost_sums", ptr(dl), ptr(p), ptr(lp2), ptr(cp2), ptr(sums), N, K, None)
+    m.call("mc_sum_all", ptr(lp), N, sep.data_ptr(), None)
+    m.call("mc_sum_all", ptr(cp), N, sep.data_ptr() + 8, None)
+    assert np.array_equal(host(lp2), host(lp)) and np.array_equal(host(cp2), host(cp)) and np.array_equal(host(sums), host(sep))
     g = nans(K, N)
     m.call("mc_compute_logreg_softmax_grad", ptr(dl), ptr(p), ptr(g), 0, 0.1, N, K, None)
     np.testing.assert_allclose(host(g), G.logreg_softmax_grad(labels, hp, 0.1), rtol=1e-6, atol=1e-7)
