@@ -173,7 +173,9 @@ int pick_gemm_chunks(int m, int n, int k) {
     // column extent less, else 96 x 128
     const bool wide = (long)ceil_div(n, 192) * 192 < (long)ceil_div(n, 128) * 128 && m > 96;
     const long tiles = wide ? (long)ceil_div(m, 128) * ceil_div(n, 192) : (long)ceil_div(m, 96) * ceil_div(n, 128);
-    if (k < 2048 || tiles >= num_cus()) return 1;
+    // a product that fits a handful of tiles is one serial K loop per workgroup (layers-80sec fc64 forward: 64 x 128 x 1024 on
+    // ONE workgroup, 64 K steps): split from k = 1024 when the tiles cover less than an eighth of the device
+    if (k < (tiles * 8 <= num_cus() ? 1024 : 2048) || tiles >= num_cus()) return 1;
     long want = (2L * num_cus() + tiles - 1) / tiles;
     const long maxc = k / 256;   // at least 256 k per chunk (8-16 LDS tiles)
     if (want > maxc) want = maxc;

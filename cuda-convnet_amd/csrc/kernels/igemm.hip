@@ -981,10 +981,11 @@ int conv_split_plan(int rows, long cols, int K, int groups, int* kChunkOut) {
     const long tiles = (long)ceil_div(rows, 96) * ceil_div(cols, 128) * groups;
     long chunks = num_cus() / tiles;
     *kChunkOut = 0;
-    if (chunks < 2 || K < 1024) return 1;
+    if (chunks < 2 || K < 512) return 1;
     if (chunks > 8) chunks = 8;
     long kc = (ceil_div(K, chunks) + 31) / 32 * 32;
-    if (kc < 512) kc = 512;
+    const long kcMin = K >= 1024 ? 512 : 256;   // mid-size K (layers-80sec conv3 forward: 800 on 64 tiles) splits into shorter chunks
+    if (kc < kcMin) kc = kcMin;
     if (kc >= K) return 1;
     *kChunkOut = (int)kc;
     return ceil_div(K, kc);
