@@ -738,15 +738,15 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
 // Tile choice.  The MFMA pipe is the bound (64 cycles per 32x32x2 per SIMD), so what matters is
 // (a) not padding the row dimension much, (b) enough workgroups to cover 256 CUs.
 // ---------------------------------------------------------------------------------
-// Tile choice.  Seven workgroup tiles are instantiated; a static rule picks one from the extents, and --
+// Tile choice.  Eight workgroup tiles are instantiated; a static rule picks one from the extents, and --
 // because the best tile depends on things the rule cannot see (how many workgroups fit a CU at that
 // register / LDS footprint, how the K chunks tail off) -- the first idempotent call of every distinct shape
 // times all of them on the caller's stream and remembers the winner (MIOpen-"find" style; off with
 // MC_IGEMM_AUTOTUNE=0, report with =2).  Every tile adds the k terms of an output element in the same
 // order, so the choice never changes a result bit; the split-K chunk count, which would, is not tuned.
 // ---------------------------------------------------------------------------------
-enum { T11, T21, T31, T51, T23, T32, T14, NTILES };
-static const char* const kTileName[NTILES] = {"32x128", "64x128", "96x128", "160x128", "128x192", "192x128", "128x32"};
+enum { T11, T21, T31, T51, T23, T32, T14, T24, NTILES };
+static const char* const kTileName[NTILES] = {"32x128", "64x128", "96x128", "160x128", "128x192", "192x128", "128x32", "128x64"};
 
 template <class AADDR, class BADDR, int BK, int VEC>
 int launch_tile(int tile, const typename AADDR::P& pa, const typename BADDR::P& pb, const ConvG& cg, const Dims& d, const Epi& ep,
@@ -760,6 +760,7 @@ int launch_tile(int tile, const typename AADDR::P& pa, const typename BADDR::P& 
         // four waves stacked over ONE 32-column strip: products with at most 64 columns (weight gradients of layers with
         // 32 / 64 filters) would otherwise run 128-column tiles that are 3/4 or 1/2 padding
         case T14: return launch_cfg<AADDR, BADDR, 1, 1, 4, 1, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+        case T24: return launch_cfg<AADDR, BADDR, 2, 1, 2, 2, BK, VEC>(pa, pb, cg, d, ep, chunks, st);   // 2x2 waves, 64 columns
         default:  return launch_cfg<AADDR, BADDR, 3, 2, 2, 2, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
     }
 }
@@ -773,6 +774,7 @@ inline int heuristic_tile(const Dims& d, int chunks) {
     const int mt32 = ceil_div(d.Mg, 32);
     const long colTiles = ceil_div(d.Ng, 128);
     if (d.Ng <= 32) return T14;   // one 32-column strip: a 128-column tile would be at least 3/4 padding
+    if (d.Ng <= 64 && d.Mg >= 128) return T24;   // two strips (weight gradients of 64-filter layers)
     if (mt32 == 5 && colTiles * z >= num_cus()) return T51;
     const long pad128 = (long)ceil_div(d.Ng, 128) * 128, pad192 = (long)ceil_div(d.Ng, 192) * 192;
     if (pad192 < pad128 && mt32 >= 4 && (long)ceil_div(d.Mg, 128) * ceil_div(d.Ng, 192) * z >= num_cus() / 2) return T23;
@@ -796,7 +798,7 @@ int launch_rows_cols(const typename AADDR::P& pa, const typename BADDR::P& pb, c
     // tuning knob (benchmarks only): MC_IGEMM_TILE="MT,NT" forces the wave tile
     static const char* forced = getenv("MC_IGEMM_TILE");
     if (forced && forced[0] && forced[1] == ',') {
-        static const int map[7][3] = {{1, 1, T11}, {2, 1, T21}, {3, 1, T31}, {5, 1, T51}, {2, 3, T23}, {3, 2, T32}, {4, 0, T14}};
+        static const int map[8][3] = {{1, 1, T11}, {2, 1, T21}, {3, 1, T31}, {5, 1, T51}, {2, 3, T23}, {3, 2, T32}, {4, 0, T14}, {4, 1, T24}};
         for (auto& m : map)
             if (forced[0] - '0' == m[0] && forced[2] - '0' == m[1]) return launch_tile<AADDR, BADDR, BK, VEC>(m[2], pa, pb, cg, d, ep, chunks, st);
     }
@@ -829,9 +831,9 @@ int launch_rows_cols(const typename AADDR::P& pa, const typename BADDR::P& pb, c
     for (int t = 0; t < NTILES; ++t) {
         ms[t] = -1.f;
         // skip tiles that would compute more than 4x the needed rows (a 160-row tile for a 10-row product)
-        static const int rowsOf[NTILES] = {32, 64, 96, 160, 128, 192, 128};
+        static const int rowsOf[NTILES] = {32, 64, 96, 160, 128, 192, 128, 128};
         if (t != rule && (long)ceil_div(d.Mg, rowsOf[t]) * rowsOf[t] > 4L * ((d.Mg + 31) / 32 * 32)) continue;
-        if (t == T14 && d.Ng > 64) continue;   // the narrow tile only where 128 columns are mostly padding
+        if ((t == T14 || t == T24) && d.Ng > 64) continue;   // the narrow tile only where 128 columns are mostly padding
         int rc = launch_tile<AADDR, BADDR, BK, VEC>(t, pa, pb, cg, d, ep, chunks, st);   // warm (and validates the launch)
         if (rc != MC_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
         (void)hipEventRecord(e0, st);
@@ -999,7 +1001,7 @@ int conv_weight_grad_plan(int N, int C, int F, int fs, int M, int groups, int* k
     const int rows = (C / groups) * fs * fs, fpg = F / groups;
     const long K = (long)M * N;
     Dims d{rows, fpg, (int)K, (int)K, groups, 0, 0, 1, 0};
-    static const int rowsOf[NTILES] = {32, 64, 96, 160, 128, 192, 128}, colsOf[NTILES] = {128, 128, 128, 128, 192, 128, 32};
+    static const int rowsOf[NTILES] = {32, 64, 96, 160, 128, 192, 128, 128}, colsOf[NTILES] = {128, 128, 128, 128, 192, 128, 32, 64};
     // the tile the static rule would take for a grid that fills the device
     const int t = heuristic_tile(d, ceil_div(num_cus(), (long)ceil_div(rows, 128) * ceil_div(fpg, 128) * groups));
     const long tiles = (long)ceil_div(rows, rowsOf[t]) * ceil_div(fpg, colsOf[t]) * groups;
