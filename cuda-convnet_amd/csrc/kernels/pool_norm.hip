@@ -266,9 +266,10 @@ __global__ void __launch_bounds__(256) k_pool_bigwin(const float* __restrict__ i
 }
 
 // ------------------------------------------------------------------ avg-pool undo
+// reluActs (nullable): the pooled images are a relu's output -- its gradient mask goes into the store (sT == 0 only)
 template <int V>
-__global__ void k_avg_undo(const float* __restrict__ avgGrads, float* target, int N, int C, int imgSize, int subsX,
-                           int startX, int strideX, int outputsX, float sT, float sO) {
+__global__ void k_avg_undo(const float* __restrict__ avgGrads, const float* __restrict__ reluActs, float* target, int N, int C, int imgSize,
+                           int subsX, int startX, int strideX, int outputsX, float sT, float sO) {
     typedef Vec<V> VV;
     const int nChunks = N / V;
     const int imgPix = imgSize * imgSize, numOut = outputsX * outputsX;
@@ -294,7 +295,8 @@ __global__ void k_avg_undo(const float* __restrict__ avgGrads, float* target, in
             }
         }
         float* t = target + (size_t)row * N + n;
-        VV::st(t, sT == 0.f ? vscale(prod, sO) : blend(VV::ld(t), prod, sT, sO));
+        if (reluActs) VV::st(t, vposmask(VV::ld(reluActs + (size_t)row * N + n), vscale(prod, sO)));
+        else VV::st(t, sT == 0.f ? vscale(prod, sO) : blend(VV::ld(t), prod, sT, sO));
     }
 }
 
@@ -506,16 +508,33 @@ int mc_conv_local_max_undo_relu_grad(const float* images, const float* maxGrads,
                           subsX, startX, strideX, outputsX, scaleTargets, scaleOutput, s);
 }
 
+static int avg_undo_entry(const char* who, const float* avgGrads, const float* reluActs, float* target, int numImages, int numFilters, int imgSize,
+                          int subsX, int startX, int strideX, int outputsX, float scaleTargets, float scaleOutput, mcStream_t s);
+
+int mc_conv_local_avg_undo_relu_grad(const float* avgGrads, const float* reluActs, float* target, int numImages, int numFilters, int imgSize,
+                                     int subsX, int startX, int strideX, int outputsX, float scaleOutput, mcStream_t s) {
+    MC_REQUIRE(reluActs, "mc_conv_local_avg_undo_relu_grad: null pointer");
+    return avg_undo_entry("mc_conv_local_avg_undo_relu_grad", avgGrads, reluActs, target, numImages, numFilters, imgSize, subsX, startX, strideX,
+                          outputsX, 0.f, scaleOutput, s);
+}
+
 int mc_conv_local_avg_undo(const float* avgGrads, float* target, int numImages, int numFilters, int imgSize, int subsX,
                            int startX, int strideX, int outputsX, float scaleTargets, float scaleOutput, mcStream_t s) {
-    MC_REQUIRE(avgGrads && target, "mc_conv_local_avg_undo: null pointer");
-    MC_POOLARGS_OK("mc_conv_local_avg_undo");
-    const bool v = use_vec(numImages, {avgGrads, target});
+    return avg_undo_entry("mc_conv_local_avg_undo", avgGrads, nullptr, target, numImages, numFilters, imgSize, subsX, startX, strideX, outputsX,
+                          scaleTargets, scaleOutput, s);
+}
+
+static int avg_undo_entry(const char* who, const float* avgGrads, const float* reluActs, float* target, int numImages, int numFilters, int imgSize,
+                          int subsX, int startX, int strideX, int outputsX, float scaleTargets, float scaleOutput, mcStream_t s) {
+    MC_REQUIRE(avgGrads && target, "%s: null pointer", who);
+    MC_REQUIRE(numImages > 0 && numFilters > 0 && imgSize > 0 && subsX > 0 && strideX > 0 && outputsX > 0, "%s: non-positive dimension", who);
+    MC_REQUIRE((size_t)numFilters * imgSize * imgSize * numImages < (1ull << 31), "%s: tensor exceeds 32-bit indexing", who);
+    const bool v = reluActs ? use_vec(numImages, {avgGrads, target, reluActs}) : use_vec(numImages, {avgGrads, target});
     const size_t items = (size_t)numFilters * imgSize * imgSize * (numImages / (v ? 4 : 1));
     dim3 g(grid_items(items)), b(TPB);
-    if (v) hipLaunchKernelGGL(k_avg_undo<4>, g, b, 0, S(s), avgGrads, target, numImages, numFilters, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput);
-    else hipLaunchKernelGGL(k_avg_undo<1>, g, b, 0, S(s), avgGrads, target, numImages, numFilters, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput);
-    return launch_status("mc_conv_local_avg_undo");
+    if (v) hipLaunchKernelGGL(k_avg_undo<4>, g, b, 0, S(s), avgGrads, reluActs, target, numImages, numFilters, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput);
+    else hipLaunchKernelGGL(k_avg_undo<1>, g, b, 0, S(s), avgGrads, reluActs, target, numImages, numFilters, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput);
+    return launch_status(who);
 }
 
 int mc_conv_contrast_norm(const float* images, const float* meanDiffs, float* denoms, float* target, int numImages,

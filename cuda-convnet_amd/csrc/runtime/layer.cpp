@@ -807,7 +807,12 @@ void AvgPoolLayer::fpropActs(int, float, PASS_TYPE) {
 }
 
 void AvgPoolLayer::bpropActs(DevMat& v, int, float scaleTargets, PASS_TYPE) {
-    RT_MC(mc_conv_local_avg_undo(v.data(), _prev[0]->getActsGrad().data(), numCases(), _channels, _imgSize, _sizeX, _start, _stride, _outputsX, scaleTargets, 1.f, ST()));
+    const float* mask = scaleTargets == 0.f ? claimReluGradMask(0) : nullptr;   // == _prev[0]->getActs()
+    if (mask)
+        RT_MC(mc_conv_local_avg_undo_relu_grad(v.data(), mask, _prev[0]->getActsGrad().data(), numCases(), _channels, _imgSize, _sizeX, _start, _stride,
+                                               _outputsX, 1.f, ST()));
+    else
+        RT_MC(mc_conv_local_avg_undo(v.data(), _prev[0]->getActsGrad().data(), numCases(), _channels, _imgSize, _sizeX, _start, _stride, _outputsX, scaleTargets, 1.f, ST()));
 }
 
 void MaxPoolLayer::fpropActs(int, float, PASS_TYPE) {

@@ -35,6 +35,7 @@ _SIGS = {
     "mc_conv_local_pool": [c_fp, c_fp] + [c_i] * 8 + [c_fp],
     "mc_conv_local_max_undo": [c_fp] * 4 + [c_i] * 7 + [c_f, c_f, c_fp],
     "mc_conv_local_avg_undo": [c_fp] * 2 + [c_i] * 7 + [c_f, c_f, c_fp],
+    "mc_conv_local_avg_undo_relu_grad": [c_fp] * 3 + [c_i] * 7 + [c_f, c_fp],
     "mc_conv_response_norm": [c_fp] * 3 + [c_i] * 4 + [c_f, c_f, c_fp],
     "mc_conv_contrast_norm": [c_fp] * 4 + [c_i] * 4 + [c_f, c_f, c_fp],
     "mc_conv_response_norm_undo": [c_fp] * 5 + [c_i] * 4 + [c_f] * 4 + [c_fp],

@@ -154,6 +154,12 @@ int mc_conv_local_max_undo_relu_grad(const float* images, const float* maxGrads,
 int mc_conv_local_avg_undo(const float* avgGrads, float* target, int numImages, int numFilters,
                            int imgSize, int subsX, int startX, int strideX, int outputsX,
                            float scaleTargets, float scaleOutput, mcStream_t stream);
+/* mc_conv_local_avg_undo followed by the relu gradient of the layer below (NeuronLayer::bpropActs with
+ * ReluNeuron, neuron.cuh:173-178) in one pass: target = reluActs > 0 ? scaleOutput * undo : 0.  reluActs are the
+ * pooled images (the relu's output), same shape as target; no accumulate form. */
+int mc_conv_local_avg_undo_relu_grad(const float* avgGrads, const float* reluActs, float* target,
+                                     int numImages, int numFilters, int imgSize, int subsX, int startX,
+                                     int strideX, int outputsX, float scaleOutput, mcStream_t stream);
 
 /* ---------------- response normalisation ----------------
  * convResponseNorm (conv_util.cu:2074-2076), convContrastNorm (:2084-2222),

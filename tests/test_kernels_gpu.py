@@ -467,6 +467,20 @@ def test_max_undo_relu_grad_equals_undo_then_relu_gradient():
         assert np.array_equal(host(got), e)
 
 
+@pytest.mark.parametrize("N,C,S,size,start,stride", [(128, 32, 16, 3, 0, 2), (128, 10, 8, 8, 0, 1), (6, 16, 6, 4, -2, 4), (5, 3, 7, 3, 0, 2)])
+def test_avg_undo_relu_grad_equals_undo_then_relu_gradient(N, C, S, size, start, stride):
+    m = mc()
+    rng = np.random.default_rng(44)
+    outX = int(np.ceil((S - start - size) / float(stride))) + 1
+    y = dev(np.maximum(rng.standard_normal((C * S * S, N)), 0))          # the relu output that was pooled
+    g = dev(rng.standard_normal((C * outX * outX, N)))
+    a, b = nans(C * S * S, N), nans(C * S * S, N)
+    m.call("mc_conv_local_avg_undo", ptr(g), ptr(a), N, C, S, size, start, stride, outX, 0.0, 1.0, None)
+    m.call("mc_neuron_input_grad", m.NEURONS["relu"], 0.0, 0.0, ptr(a), ptr(y), ptr(a), 0, a.numel(), None)
+    m.call("mc_conv_local_avg_undo_relu_grad", ptr(g), ptr(y), ptr(b), N, C, S, size, start, stride, outX, 1.0, None)
+    assert np.array_equal(host(a), host(b))
+
+
 @pytest.mark.parametrize("N,C,H,fs,F,pad,stride,groups", [(128, 32, 16, 5, 32, 2, 1, 1), (16, 3, 32, 5, 32, 2, 1, 1), (32, 96, 8, 5, 192, 2, 1, 1),
                                                          (128, 192, 8, 3, 192, 1, 1, 1), (12, 8, 9, 3, 16, 1, 2, 2), (5, 3, 10, 5, 4, 0, 1, 1)])
 def test_conv_weight_grad_free_chunking(N, C, H, fs, F, pad, stride, groups):
