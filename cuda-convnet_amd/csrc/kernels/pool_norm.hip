@@ -50,8 +50,12 @@ __device__ __forceinline__ float4 vposmask(float4 y, float4 v) {
 __device__ __forceinline__ float vposmask(float y, float v) { return y > 0.f ? v : 0.f; }
 __device__ __forceinline__ float4 vfma_s(float s, float4 a, float4 c) { return make_float4(s * a.x + c.x, s * a.y + c.y, s * a.z + c.z, s * a.w + c.w); }
 __device__ __forceinline__ float vfma_s(float s, float a, float c) { return s * a + c; }
-__device__ __forceinline__ float4 vpow(float4 a, float e) { return make_float4(powf(a.x, e), powf(a.y, e), powf(a.z, e), powf(a.w, e)); }
-__device__ __forceinline__ float vpow(float a, float e) { return powf(a, e); }
+// a^e for a > 0 as exp2(e * log2 a) on the hardware transcendental units -- what the reference's __powf compiles to
+// (conv_util.cu:895, 1086).  The library powf is ~100 instructions an element and made the norm kernels ALU-bound
+// (cmrnorm forward at 2.5 TB/s); denominators are >= k = 1 here, where this form is accurate to a few 1e-7 relative.
+__device__ __forceinline__ float fast_pow(float a, float e) { return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(a)); }
+__device__ __forceinline__ float4 vpow(float4 a, float e) { return make_float4(fast_pow(a.x, e), fast_pow(a.y, e), fast_pow(a.z, e), fast_pow(a.w, e)); }
+__device__ __forceinline__ float vpow(float a, float e) { return fast_pow(a, e); }
 
 template <class T>
 __device__ __forceinline__ T blend(T old, T v, float sT, float sO) { return vadd(vscale(old, sT), vscale(v, sO)); }
@@ -391,6 +395,46 @@ __global__ void k_cmrnorm(const float* __restrict__ imgs, float* denoms, float* 
     }
 }
 
+// The same sums for the centred (not blocked) window of SF maps, walking the map axis: one lane owns a (pixel, image)
+// column and a segment of maps, keeps the window's SF inputs in registers and re-adds their squares in map order at
+// every step, so each input is read once (plus SF-1 halo maps per segment) instead of SF times, and the sum has the
+// order -- and the bits -- of k_cmrnorm (maps outside [0, C) enter as +0).
+template <int V, int SF>
+__global__ void k_cmrnorm_walk(const float* __restrict__ imgs, float* denoms, float* target, int N, int C, int imgPix, int segLen,
+                               float addScale, float powScale, float k) {
+    typedef Vec<V> VV;
+    typedef typename VV::T T;
+    const int nChunks = N / V;
+    const int nSeg = (C + segLen - 1) / segLen;
+    const size_t total = (size_t)nSeg * imgPix * nChunks;
+    for (size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(item % nChunks) * V;
+        const size_t rest = item / nChunks;
+        const int px = (int)(rest % imgPix), seg = (int)(rest / imgPix);
+        const int c0 = seg * segLen, c1 = min(C, c0 + segLen);
+        const size_t col = (size_t)px * N + n, mapStride = (size_t)imgPix * N;
+        T x[SF];
+#pragma unroll
+        for (int j = 0; j < SF - 1; ++j) {   // window of map c0, all but its last member
+            const int f = c0 - SF / 2 + j;
+            x[j + 1] = (f >= 0 && f < C) ? VV::ld(imgs + f * mapStride + col) : VV::splat(0.f);
+        }
+        for (int c = c0; c < c1; ++c) {
+#pragma unroll
+            for (int j = 0; j < SF - 1; ++j) x[j] = x[j + 1];
+            const int f = c - SF / 2 + SF - 1;
+            x[SF - 1] = f < C ? VV::ld(imgs + f * mapStride + col) : VV::splat(0.f);
+            T sum = VV::splat(0.f);
+#pragma unroll
+            for (int j = 0; j < SF; ++j) sum = vadd(sum, vmul(x[j], x[j]));
+            const T d = vfma_s(addScale, sum, VV::splat(k));
+            const size_t i = c * mapStride + col;
+            VV::st(denoms + i, d);
+            VV::st(target + i, vmul(x[SF / 2], vpow(d, -powScale)));
+        }
+    }
+}
+
 template <int V>
 __global__ void k_cmrnorm_undo(const float* __restrict__ outGrads, const float* __restrict__ denoms,
                                const float* __restrict__ inputs, const float* __restrict__ acts, float* target, int N,
@@ -584,6 +628,14 @@ int mc_conv_response_norm_cross_map(const float* images, float* denoms, float* t
     MC_REQUIRE(numImages > 0 && numFilters > 0 && imgSize > 0 && sizeF > 0 && sizeF <= numFilters, "mc_conv_response_norm_cross_map: bad dimension");
     const bool v = use_vec(numImages, {images, denoms, target});
     const size_t items = (size_t)numFilters * imgSize * imgSize * (numImages / (v ? 4 : 1));
+    static const bool nowalk = getenv("MC_CMRNORM_NOWALK") != nullptr;
+    if (!blocked && sizeF == 5 && numFilters >= 16 && !nowalk) {   // the centred 5-map window of the shipped configs
+        const int segLen = 16, nSeg = ceil_div(numFilters, segLen);
+        dim3 gw(grid_items((size_t)nSeg * imgSize * imgSize * (numImages / (v ? 4 : 1)))), bw(TPB);
+        if (v) hipLaunchKernelGGL((k_cmrnorm_walk<4, 5>), gw, bw, 0, S(s), images, denoms, target, numImages, numFilters, imgSize * imgSize, segLen, addScale, powScale, k);
+        else hipLaunchKernelGGL((k_cmrnorm_walk<1, 5>), gw, bw, 0, S(s), images, denoms, target, numImages, numFilters, imgSize * imgSize, segLen, addScale, powScale, k);
+        return launch_status("mc_conv_response_norm_cross_map");
+    }
     dim3 g(grid_items(items)), b(TPB);
     if (v) hipLaunchKernelGGL(k_cmrnorm<4>, g, b, 0, S(s), images, denoms, target, numImages, numFilters, imgSize, sizeF, addScale, powScale, blocked, k);
     else hipLaunchKernelGGL(k_cmrnorm<1>, g, b, 0, S(s), images, denoms, target, numImages, numFilters, imgSize, sizeF, addScale, powScale, blocked, k);
