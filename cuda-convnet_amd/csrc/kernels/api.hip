@@ -3,6 +3,8 @@
 // fp32-MFMA engine as batched products (igemm.hip: one product per module forward, one per pixel backward).
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
+#include <vector>
 #include "mc_common.h"
 
 namespace mc {
@@ -38,6 +40,7 @@ int conv_split_plan(int, long, int, int, int*);
 int conv_weight_acts_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int, int, int, int,
                           float, float, hipStream_t);
 int conv_weight_grad_plan(int, int, int, int, int, int, int*);
+void set_tune_inhibit(bool);
 int gemm_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, float, float, const float*, int,
               const float*, int, int, long, hipStream_t);
 
@@ -134,20 +137,30 @@ __global__ void k_splitk_reduce4(const float4* __restrict__ slabs, float* C, int
 }
 
 // Library-owned scratch for the split-K slabs of the conv forward / backward-data entry points, whose signatures (the
-// reference's host wrappers) carry no workspace: one grow-only buffer per host thread and device, allocated on first
-// need.  Calls that share it must be ordered on one stream (the runtime's compute stream is).
-float* split_scratch(size_t bytes) {
-    struct Buf { float* p = nullptr; size_t cap = 0; int dev = -1; };
-    static thread_local Buf b;
+// reference's host wrappers) carry no workspace.  One grow-only buffer per (device, stream): calls on one stream are ordered,
+// so they may share it; calls on different streams never do.  A buffer that has become too small is RETIRED, not freed
+// (launches already queued may still be using it): nothing here synchronises or frees, and the only hipMalloc is the
+// growth itself.  mc_reserve_conv_split_workspace() sizes it ahead of time (the runtime does at initModel), after
+// which these entry points allocate nothing.
+struct SplitBuf { int dev; hipStream_t st; float* p; size_t cap; };
+static std::mutex g_splitMu;
+static std::vector<SplitBuf> g_splitBufs;
+
+float* split_scratch(size_t bytes, hipStream_t st) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    if (b.dev != dev || b.cap < bytes) {
-        if (b.p && b.dev == dev) { (void)hipDeviceSynchronize(); (void)hipFree(b.p); }
-        b.p = nullptr; b.cap = 0; b.dev = dev;
-        if (hipMalloc(reinterpret_cast<void**>(&b.p), bytes) != hipSuccess) { b.p = nullptr; return nullptr; }
-        b.cap = bytes;
-    }
-    return b.p;
+    std::lock_guard<std::mutex> lk(g_splitMu);
+    SplitBuf* b = nullptr;
+    for (auto& e : g_splitBufs)
+        if (e.dev == dev && e.st == st) { b = &e; break; }
+    if (b && b->cap >= bytes) return b->p;
+    size_t cap = (bytes + ((size_t)1 << 20) - 1) >> 20 << 20;
+    if (b && cap < b->cap + b->cap / 2) cap = b->cap + b->cap / 2;   // geometric growth bounds what the retired buffers hold
+    float* p = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&p), cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (b) { b->p = p; b->cap = cap; }   // the old buffer stays allocated until the process ends
+    else g_splitBufs.push_back(SplitBuf{dev, st, p, cap});
+    return p;
 }
 
 inline int grid_items(size_t items) {
@@ -228,7 +241,7 @@ int mc_conv_filter_acts_fused(const float* images, const float* filters, float* 
         const long cols = (long)numModulesY * numModulesX * numImages;
         int kc = 0;
         const int chunks = conv_split_plan(numFilters / numGroups, cols, numImgColors / numGroups * filterSize * filterSize, numGroups, &kc);
-        float* slabs = chunks > 1 ? split_scratch((size_t)chunks * numFilters * cols * sizeof(float)) : nullptr;
+        float* slabs = chunks > 1 ? split_scratch((size_t)chunks * numFilters * cols * sizeof(float), S(s)) : nullptr;
         if (slabs) {
             int rc = conv_filter_acts_impl(images, filters, targets, nullptr, MC_NEURON_NONE, numImages, numImgColors, imgSizeY, imgSizeX,
                                            numFilters, filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 0,
@@ -251,7 +264,7 @@ int mc_conv_img_acts(const float* hidActs, const float* filters, float* targets,
         const long cols = (long)imgSizeY * imgSizeX * numImages;
         int kc = 0;
         const int chunks = conv_split_plan(numImgColors / numGroups, cols, filterSize * filterSize * (numFilters / numGroups), numGroups, &kc);
-        float* slabs = chunks > 1 ? split_scratch((size_t)chunks * numImgColors * cols * sizeof(float)) : nullptr;
+        float* slabs = chunks > 1 ? split_scratch((size_t)chunks * numImgColors * cols * sizeof(float), S(s)) : nullptr;
         if (slabs) {
             int rc = conv_img_acts_impl(hidActs, filters, targets, numImages, numImgColors, imgSizeY, imgSizeX, numFilters, filterSize,
                                         paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 0, 0.f, 1.f, slabs, kc, S(s));
@@ -406,6 +419,27 @@ int mc_conv_weight_grad(const float* images, const float* hidActs, float* weight
                                    paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 0, kc, 0.f, 1.f, S(s));
     if (rc) return rc;
     return mc_sum_cols(slabs, weightGrad, chunks, (int)wel, scaleTargets, scaleOutput, s);
+}
+
+
+size_t mc_conv_split_workspace_bytes(int numImages, int numImgColors, int imgSizeY, int imgSizeX, int numFilters, int filterSize,
+                                     int numModulesY, int numModulesX, int numGroups) {
+    if (numImages <= 0 || numImgColors <= 0 || numFilters <= 0 || numGroups <= 0 || filterSize <= 0 || numModulesY <= 0 || numModulesX <= 0 ||
+        imgSizeY <= 0 || imgSizeX <= 0 || numFilters % numGroups || numImgColors % numGroups)
+        return 0;
+    int kc = 0;
+    const long fcols = (long)numModulesY * numModulesX * numImages, bcols = (long)imgSizeY * imgSizeX * numImages;
+    const int fch = conv_split_plan(numFilters / numGroups, fcols, numImgColors / numGroups * filterSize * filterSize, numGroups, &kc);
+    const int bch = conv_split_plan(numImgColors / numGroups, bcols, filterSize * filterSize * (numFilters / numGroups), numGroups, &kc);
+    const size_t f = fch > 1 ? (size_t)fch * numFilters * fcols * sizeof(float) : 0;
+    const size_t b = bch > 1 ? (size_t)bch * numImgColors * bcols * sizeof(float) : 0;
+    return f > b ? f : b;
+}
+
+int mc_reserve_conv_split_workspace(size_t bytes, mcStream_t s) {
+    if (bytes == 0) return MC_OK;
+    if (!split_scratch(bytes, S(s))) { set_error("mc_reserve_conv_split_workspace: cannot allocate %zu bytes", bytes); return MC_EWORKSPACE; }
+    return MC_OK;
 }
 
 }  // extern "C"

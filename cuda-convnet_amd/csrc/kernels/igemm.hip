@@ -32,6 +32,7 @@
 #include <map>
 #include <type_traits>
 #include <mutex>
+#include <atomic>
 #include "mc_common.h"
 
 #ifdef MC_STAMP   // diagnostic build only (tools/build_variant.sh stamp -DMC_STAMP): where do the K steps spend their cycles?
@@ -708,10 +709,15 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = mc_igemm<AADDR, BADDR, MT, NT, WM, WN, BK, VEC, NS>;
     Dims d = d0;
-    static bool attr_done = false;
-    if (lds > 48 * 1024 && !attr_done) {
+    // per-device state of this instantiation (a function attribute belongs to the device's own code object)
+    static std::atomic<unsigned long long> attrDone{0};
+    static std::atomic<int> perCU[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    if (lds > 48 * 1024 && !((attrDone.load(std::memory_order_acquire) >> dev) & 1ull)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
+        attrDone.fetch_or(1ull << dev, std::memory_order_release);
     }
     dim3 grid(ceil_div(d.Ng, BN), ceil_div(d.Mg, BM), chunks * d.groups * d.batches);
     d.colTiles = (int)grid.x;
@@ -720,12 +726,13 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
     const int stepsPerTile = ceil_div(d.kChunk < d.Kg ? d.kChunk : d.Kg, BK);
     static const bool nopersist = getenv("MC_IGEMM_NOPERSIST") != nullptr;
     if (!nopersist && stepsPerTile <= 24 && (long)grid.x * grid.y * grid.z > 2L * num_cus()) {
-        static int perCU = 0;
-        if (perCU == 0) {
+        int pc = perCU[dev].load(std::memory_order_relaxed);
+        if (pc == 0) {
             int nb = 0;
-            perCU = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 2 * THREADS, lds) == hipSuccess && nb > 0) ? nb : 1;
+            pc = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 2 * THREADS, lds) == hipSuccess && nb > 0) ? nb : 1;
+            perCU[dev].store(pc, std::memory_order_relaxed);
         }
-        long workers = (long)perCU * num_cus() / ((long)grid.y * grid.z);
+        long workers = (long)pc * num_cus() / ((long)grid.y * grid.z);
         if (workers >= 8) workers = workers / 8 * 8;
         if (workers >= 1 && workers < (long)grid.x) grid.x = (unsigned)workers;
     }
@@ -791,6 +798,7 @@ struct TuneKey {
 };
 static std::map<TuneKey, int> g_tuned;
 static std::mutex g_tuneMu;
+static thread_local bool g_tuneInhibit = false;
 
 template <class AADDR, class BADDR, int BK, int VEC>
 int launch_rows_cols(const typename AADDR::P& pa, const typename BADDR::P& pb, const ConvG& cg, const Dims& d,
@@ -820,8 +828,9 @@ int launch_rows_cols(const typename AADDR::P& pa, const typename BADDR::P& pb, c
         auto it = g_tuned.find(key);
         if (it != g_tuned.end()) return launch_tile<AADDR, BADDR, BK, VEC>(it->second, pa, pb, cg, d, ep, chunks, st);
     }
-    // an accumulating call (scaleTargets != 0) is not idempotent: serve it by the rule and let a later plain call tune
-    if (ep.beta != 0.f) return launch_tile<AADDR, BADDR, BK, VEC>(rule, pa, pb, cg, d, ep, chunks, st);
+    // an accumulating call (scaleTargets != 0) is not idempotent: serve it by the rule and let a later plain call tune;
+    // so is a call from an entry point that must not create events or block (mc_conv_weight_grad_noalloc)
+    if (ep.beta != 0.f || g_tuneInhibit) return launch_tile<AADDR, BADDR, BK, VEC>(rule, pa, pb, cg, d, ep, chunks, st);
 
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
@@ -886,6 +895,9 @@ int make_convg(ConvG& cg, int N, int C, int H, int W, int F, int fs, int pad, in
 }
 
 }  // namespace
+
+// While set (per host thread), a shape that has not been tuned yet runs the static rule's tile instead of the timed trial.
+void set_tune_inhibit(bool on) { g_tuneInhibit = on; }
 
 // =================================================================================
 // conv forward: C[f][(m,n)] ; Mg = F/groups, Ng = M*N, Kg = fc*fp

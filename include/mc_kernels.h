@@ -103,6 +103,16 @@ int mc_conv_weight_grad(const float* images, const float* hidActs, float* weight
                         int numGroups, float scaleTargets, float scaleOutput, void* workspace,
                         size_t workspaceBytes, mcStream_t stream);
 
+/* Split-K scratch of mc_conv_filter_acts(_fused) / mc_conv_img_acts (layers with few modules, e.g. NIN conv3: the K
+ * axis is cut so the launch fills the device).  Their signatures are the reference's host wrappers' and carry no
+ * workspace, so the library keeps one grow-only buffer per (device, stream).  mc_conv_split_workspace_bytes gives
+ * what a layer's forward / backward-data calls need (0 = no split); mc_reserve_conv_split_workspace sizes the
+ * buffer of `stream` on the current device ahead of time, after which those entry points allocate nothing. */
+size_t mc_conv_split_workspace_bytes(int numImages, int numImgColors, int imgSizeY, int imgSizeX,
+                                     int numFilters, int filterSize, int numModulesY, int numModulesX,
+                                     int numGroups);
+int mc_reserve_conv_split_workspace(size_t bytes, mcStream_t stream);
+
 /* A partialSum the library considers a good split of the module axis for this shape on this
  * device (divides numModules; the reference takes it from the layer-def file instead). */
 int mc_conv_weight_acts_pick_partial_sum(int numImages, int numImgColors, int numFilters,
