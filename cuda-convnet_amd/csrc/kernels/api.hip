@@ -442,4 +442,68 @@ int mc_reserve_conv_split_workspace(size_t bytes, mcStream_t s) {
     return MC_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The entry point that allocates nothing.  mc_conv_weight_grad's split-K slabs (the workspace argument there) live in a
+// file-scope device array instead; its device address is looked up once per device with hipGetSymbolAddress and only
+// that pointer is ever handed to kernels.
+// ---------------------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+constexpr size_t kStaticScratchBytes = MC_NOALLOC_SCRATCH_BYTES;
+static __device__ __align__(256) float scratch[kStaticScratchBytes / sizeof(float)];
+constexpr int kMaxDevices = 64;
+static std::mutex g_scratchMu;
+static float* g_scratchPtr[kMaxDevices];   // device address of `scratch` on each device, filled on first use
+
+// `scratch` as a name is a host-side handle: only the address hipGetSymbolAddress returns for the CURRENT device is real
+int static_scratch(float** out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { set_error("mc_conv_weight_grad_noalloc: hipGetDevice: %s", hipGetErrorString(e)); return MC_ELAUNCH; }
+    if (dev < 0 || dev >= kMaxDevices) { set_error("mc_conv_weight_grad_noalloc: device ordinal %d not supported (max %d)", dev, kMaxDevices - 1); return MC_EINVAL; }
+    std::lock_guard<std::mutex> lk(g_scratchMu);
+    if (!g_scratchPtr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            set_error("mc_conv_weight_grad_noalloc: hipGetSymbolAddress(scratch): %s", hipGetErrorString(e));
+            return MC_ELAUNCH;
+        }
+        g_scratchPtr[dev] = static_cast<float*>(p);
+    }
+    *out = g_scratchPtr[dev];
+    return MC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+size_t mc_noalloc_scratch_bytes(void) { return kStaticScratchBytes; }
+
+int mc_conv_weight_grad_noalloc(const float* images, const float* hidActs, float* weightGrad, int numImages, int numImgColors,
+                                int imgSizeY, int imgSizeX, int numFilters, int filterSize, int paddingStart, int moduleStride,
+                                int numModulesY, int numModulesX, int numGroups, float scaleTargets, float scaleOutput,
+                                mcStream_t s) {
+    MC_REQUIRE(images && hidActs && weightGrad, "mc_conv_weight_grad_noalloc: null pointer");
+    const size_t need = mc_conv_weight_grad_workspace_bytes(numImages, numImgColors, numFilters, filterSize,
+                                                            numModulesY > 0 && numModulesX > 0 ? numModulesY * numModulesX : 0, numGroups);
+    if (need > kStaticScratchBytes) {
+        set_error("mc_conv_weight_grad_noalloc: this shape needs %zu bytes of split-K scratch, the library's static array holds %zu; "
+                  "use mc_conv_weight_grad with a workspace", need, kStaticScratchBytes);
+        return MC_EWORKSPACE;
+    }
+    float* ws = nullptr;
+    int rc = static_scratch(&ws);
+    if (rc) return rc;
+    // every slab element the reduction reads is written by the product first (chunks cover the whole (module, image) axis),
+    // so nothing left in the array by an earlier call is ever read: no clearing needed
+    set_tune_inhibit(true);   // the timed tile trial creates events and blocks: not from this entry point
+    rc = mc_conv_weight_grad(images, hidActs, weightGrad, numImages, numImgColors, imgSizeY, imgSizeX, numFilters, filterSize,
+                             paddingStart, moduleStride, numModulesY, numModulesX, numGroups, scaleTargets, scaleOutput, ws,
+                             kStaticScratchBytes, s);
+    set_tune_inhibit(false);
+    return rc;
+}
+
 }  // extern "C"

@@ -30,6 +30,7 @@ _SIGS = {
     "mc_conv_weight_acts_pick_partial_sum": [c_i] * 6,
     "mc_gemm": [c_fp, c_fp, c_fp] + [c_i] * 8 + [c_f, c_f, c_fp, c_i, c_fp, c_sz, c_fp],
     "mc_conv_weight_grad": [c_fp, c_fp, c_fp] + [c_i] * 11 + [c_f, c_f, c_fp, c_sz, c_fp],
+    "mc_conv_weight_grad_noalloc": [c_fp, c_fp, c_fp] + [c_i] * 11 + [c_f, c_f, c_fp],
     "mc_reserve_conv_split_workspace": [c_sz, c_fp],
     "mc_gemm_relu_grad": [c_fp, c_fp, c_fp] + [c_i] * 8 + [c_f, c_f, c_fp, c_i, c_fp, c_sz, c_fp],
     "mc_conv_local_max_undo_relu_grad": [c_fp] * 4 + [c_i] * 7 + [c_f, c_f, c_fp],
@@ -91,7 +92,7 @@ class McError(RuntimeError):
 def exported_symbols():
     """Names every build of the library must export (those include/mc_kernels.h declares)."""
     return sorted(list(_SIGS) + ["mc_last_error", "mc_gemm_workspace_bytes", "mc_conv_weight_grad_workspace_bytes",
-                                   "mc_conv_split_workspace_bytes"])
+                                   "mc_noalloc_scratch_bytes", "mc_conv_split_workspace_bytes"])
 
 
 def lib():
@@ -110,6 +111,8 @@ def lib():
         L.mc_gemm_workspace_bytes.restype = c_sz
         L.mc_conv_weight_grad_workspace_bytes.argtypes = [c_i] * 6
         L.mc_conv_weight_grad_workspace_bytes.restype = c_sz
+        L.mc_noalloc_scratch_bytes.argtypes = []
+        L.mc_noalloc_scratch_bytes.restype = c_sz
         L.mc_conv_split_workspace_bytes.argtypes = [c_i] * 9
         L.mc_conv_split_workspace_bytes.restype = c_sz
         _lib = L

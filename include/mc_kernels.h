@@ -103,6 +103,22 @@ int mc_conv_weight_grad(const float* images, const float* hidActs, float* weight
                         int numGroups, float scaleTargets, float scaleOutput, void* workspace,
                         size_t workspaceBytes, mcStream_t stream);
 
+/* mc_conv_weight_grad for callers that cannot allocate device memory or hand over a workspace: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE.  The split-K slabs live
+ * in a device array owned by the library (MC_NOALLOC_SCRATCH_BYTES per GPU the library runs on, held until the process
+ * ends); the call performs no hipMalloc / hipFree, creates no events and never blocks (the tile autotuner is skipped:
+ * a shape not tuned yet runs the static rule's tile -- same bits either way).  Output is bit-identical to
+ * mc_conv_weight_grad.  A shape whose slabs exceed the array (mc_conv_weight_grad_workspace_bytes(...) >
+ * mc_noalloc_scratch_bytes()) is rejected with MC_EWORKSPACE.  Every call on a GPU shares that GPU's array: calls that
+ * overlap on one GPU (different streams / threads) race; order them on one stream. */
+#define MC_NOALLOC_SCRATCH_BYTES ((size_t)32 << 20)
+size_t mc_noalloc_scratch_bytes(void);
+int mc_conv_weight_grad_noalloc(const float* images, const float* hidActs, float* weightGrad,
+                                int numImages, int numImgColors, int imgSizeY, int imgSizeX,
+                                int numFilters, int filterSize, int paddingStart, int moduleStride,
+                                int numModulesY, int numModulesX, int numGroups, float scaleTargets,
+                                float scaleOutput, mcStream_t stream);
+
 /* Split-K scratch of mc_conv_filter_acts(_fused) / mc_conv_img_acts (layers with few modules, e.g. NIN conv3: the K
  * axis is cut so the launch fills the device).  Their signatures are the reference's host wrappers' and carry no
  * workspace, so the library keeps one grow-only buffer per (device, stream).  mc_conv_split_workspace_bytes gives
