@@ -33,7 +33,7 @@ int num_cus() {
 
 // implemented in igemm.hip
 int conv_filter_acts_impl(const float*, const float*, float*, const float*, int, int, int, int, int, int, int, int, int, int,
-                          int, int, int, float, float, float*, int, hipStream_t);
+                          int, int, int, float, float, float*, int, unsigned*, hipStream_t);
 int conv_img_acts_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int, int, int, float,
                        float, float*, int, hipStream_t);
 int conv_split_plan(int, long, int, int, int*);
@@ -42,7 +42,7 @@ int conv_weight_acts_impl(const float*, const float*, float*, int, int, int, int
 int conv_weight_grad_plan(int, int, int, int, int, int, int*);
 void set_tune_inhibit(bool);
 int gemm_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, float, float, const float*, int,
-              const float*, int, int, long, hipStream_t);
+              const float*, int, int, long, unsigned*, const unsigned*, hipStream_t);
 
 namespace {
 
@@ -133,6 +133,47 @@ __global__ void k_splitk_reduce4(const float4* __restrict__ slabs, float* C, int
         if (bias) { const float b = bias[i]; v.x += b; v.y += b; v.z += b; v.w += b; }
         if (act == MC_NEURON_RELU) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }
         *dst = v;
+    }
+}
+
+// ---- relu bit masks (layout: mc_kernels.h "relu bit masks"): word (i >> 5) * ld + j, bit p = 16 * h + r <-> row
+// (i & ~31) + (r & 3) + 8 * (r >> 2) + 4 * h.  Thread = (32-row block, column): walks the block's rows in bit order.
+__device__ __forceinline__ int bit_row(int p) { const int h = p >> 4, r = p & 15; return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// split-K reduction that also writes the bit mask of its (relu) output: out = alpha * sum_q slab[q] (+bias) (relu), bit = out > 0
+__global__ void k_splitk_reduce_bits(const float* __restrict__ slabs, float* C, unsigned* bits, int m, int n, int chunks, float alpha,
+                                     const float* __restrict__ bias, int act) {
+    const size_t total = (size_t)m * n;
+    const int blocks32 = (m + 31) >> 5;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < (size_t)blocks32 * n; t += (size_t)gridDim.x * blockDim.x) {
+        const int rb = (int)(t / n), j = (int)(t - (size_t)rb * n);
+        unsigned w = 0;
+        for (int p = 0; p < 32; ++p) {
+            const int i = rb * 32 + bit_row(p);
+            if (i >= m) continue;
+            const size_t e = (size_t)i * n + j;
+            float acc = 0.f;
+            for (int q = 0; q < chunks; ++q) acc += slabs[(size_t)q * total + e];
+            float v = alpha * acc;
+            if (bias) v += bias[i];
+            if (act == MC_NEURON_RELU) v = v < 0.f ? 0.f : v;
+            C[e] = v;
+            w |= (v > 0.f) ? (1u << p) : 0u;
+        }
+        bits[t] = w;
+    }
+}
+
+__global__ void k_relu_bits_from_acts(const float* __restrict__ acts, unsigned* bits, int m, int n, int ld) {
+    const int blocks32 = (m + 31) >> 5;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < (size_t)blocks32 * n; t += (size_t)gridDim.x * blockDim.x) {
+        const int rb = (int)(t / n), j = (int)(t - (size_t)rb * n);
+        unsigned w = 0;
+        for (int p = 0; p < 32; ++p) {
+            const int i = rb * 32 + bit_row(p);
+            if (i < m && acts[(size_t)i * ld + j] > 0.f) w |= 1u << p;
+        }
+        bits[(size_t)rb * ld + j] = w;
     }
 }
 
@@ -229,10 +270,31 @@ int mc_conv_filter_acts(const float* images, const float* filters, float* target
                                      scaleTargets, scaleOutput, s);
 }
 
+static int conv_fwd_entry(const float* images, const float* filters, float* targets, const float* biases, int neuron,
+                          int numImages, int numImgColors, int imgSizeY, int imgSizeX, int numFilters, int filterSize,
+                          int paddingStart, int moduleStride, int numModulesY, int numModulesX, int numGroups,
+                          float scaleTargets, float scaleOutput, unsigned* reluBits, mcStream_t s);
+
 int mc_conv_filter_acts_fused(const float* images, const float* filters, float* targets, const float* biases, int neuron,
                               int numImages, int numImgColors, int imgSizeY, int imgSizeX, int numFilters, int filterSize,
                               int paddingStart, int moduleStride, int numModulesY, int numModulesX, int numGroups,
                               float scaleTargets, float scaleOutput, mcStream_t s) {
+    return conv_fwd_entry(images, filters, targets, biases, neuron, numImages, numImgColors, imgSizeY, imgSizeX, numFilters, filterSize,
+                          paddingStart, moduleStride, numModulesY, numModulesX, numGroups, scaleTargets, scaleOutput, nullptr, s);
+}
+
+int mc_conv_filter_acts_relu_bits(const float* images, const float* filters, float* targets, const float* biases, unsigned* reluBits,
+                                  int numImages, int numImgColors, int imgSizeY, int imgSizeX, int numFilters, int filterSize,
+                                  int paddingStart, int moduleStride, int numModulesY, int numModulesX, mcStream_t s) {
+    MC_REQUIRE(reluBits, "mc_conv_filter_acts_relu_bits: null reluBits");
+    return conv_fwd_entry(images, filters, targets, biases, MC_NEURON_RELU, numImages, numImgColors, imgSizeY, imgSizeX, numFilters,
+                          filterSize, paddingStart, moduleStride, numModulesY, numModulesX, 1, 0.f, 1.f, reluBits, s);
+}
+
+static int conv_fwd_entry(const float* images, const float* filters, float* targets, const float* biases, int neuron,
+                          int numImages, int numImgColors, int imgSizeY, int imgSizeX, int numFilters, int filterSize,
+                          int paddingStart, int moduleStride, int numModulesY, int numModulesX, int numGroups,
+                          float scaleTargets, float scaleOutput, unsigned* reluBits, mcStream_t s) {
     MC_REQUIRE(images && filters && targets, "mc_conv_filter_acts_fused: null pointer");
     MC_REQUIRE(neuron == MC_NEURON_NONE || neuron == MC_NEURON_RELU, "mc_conv_filter_acts_fused: unknown neuron %d", neuron);
     // few columns (modules x images): split K so the grid fills the device, reduce the slabs with the epilogue
@@ -245,14 +307,19 @@ int mc_conv_filter_acts_fused(const float* images, const float* filters, float* 
         if (slabs) {
             int rc = conv_filter_acts_impl(images, filters, targets, nullptr, MC_NEURON_NONE, numImages, numImgColors, imgSizeY, imgSizeX,
                                            numFilters, filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 0,
-                                           0.f, 1.f, slabs, kc, S(s));
+                                           0.f, 1.f, slabs, kc, nullptr, S(s));
             if (rc) return rc;
+            if (reluBits) {
+                hipLaunchKernelGGL(k_splitk_reduce_bits, dim3(grid_items((size_t)ceil_div(numFilters, 32) * cols)), dim3(TPB), 0, S(s), slabs, targets,
+                                   reluBits, numFilters, (int)cols, chunks, scaleOutput, biases, neuron);
+                return launch_status("conv split-K reduce (bits)");
+            }
             return reduce_slabs(slabs, targets, numFilters, cols, chunks, scaleOutput, scaleTargets, biases, neuron, S(s));
         }
     }
     return conv_filter_acts_impl(images, filters, targets, biases, neuron, numImages, numImgColors, imgSizeY, imgSizeX,
                                  numFilters, filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 0,
-                                 scaleTargets, scaleOutput, nullptr, 0, S(s));
+                                 scaleTargets, scaleOutput, nullptr, 0, reluBits, S(s));
 }
 
 int mc_conv_img_acts(const float* hidActs, const float* filters, float* targets, int numImages, int numImgColors,
@@ -322,7 +389,7 @@ int mc_local_filter_acts(const float* images, const float* filters, float* targe
     MC_REQUIRE(images && filters && targets, "mc_local_filter_acts: null pointer");
     return conv_filter_acts_impl(images, filters, targets, nullptr, MC_NEURON_NONE, numImages, numImgColors, imgSizeY, imgSizeX,
                                  numFilters, filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 1,
-                                 scaleTargets, scaleOutput, nullptr, 0, S(s));
+                                 scaleTargets, scaleOutput, nullptr, 0, nullptr, S(s));
 }
 
 int mc_local_img_acts(const float* hidActs, const float* filters, float* targets, int numImages, int numImgColors,
@@ -342,7 +409,8 @@ size_t mc_gemm_workspace_bytes(int m, int n, int k) {
 
 static int gemm_entry(const char* who, const float* A, const float* B, float* C, int m, int n, int k, int transA, int transB, int lda,
                       int ldb, int ldc, float scaleTargets, float scaleOutput, const float* rowBias, int neuron, const float* mask,
-                      int ldmask, void* workspace, size_t workspaceBytes, mcStream_t s) {
+                      int ldmask, void* workspace, size_t workspaceBytes, mcStream_t s, unsigned* bitsOut = nullptr,
+                      const unsigned* bitsIn = nullptr) {
     MC_REQUIRE(A && B && C, "%s: null pointer", who);
     MC_REQUIRE(m > 0 && n > 0 && k > 0, "%s: non-positive dimension (%d,%d,%d)", who, m, n, k);
     MC_REQUIRE(lda >= (transA ? m : k) && ldb >= (transB ? k : n) && ldc >= n, "%s: leading dimension too small", who);
@@ -351,11 +419,11 @@ static int gemm_entry(const char* who, const float* A, const float* B, float* C,
     MC_REQUIRE((size_t)(transA ? k : m) * lda < (1ull << 30) && (size_t)(transB ? n : k) * ldb < (1ull << 30) &&
                    (size_t)m * ldc < (1ull << 30) && (!mask || (size_t)m * ldmask < (1ull << 30)),
                "%s: operand exceeds the 4 GiB buffer-descriptor range", who);
-    int chunks = pick_gemm_chunks(m, n, k);
+    int chunks = (bitsOut || bitsIn) ? 1 : pick_gemm_chunks(m, n, k);   // the bit-mask epilogues live in the unsplit product
     if (chunks > 1 && workspace && workspaceBytes >= (size_t)chunks * m * n * sizeof(float) && aligned16(workspace)) {
         float* slabs = static_cast<float*>(workspace);
         int rc = gemm_impl(A, B, slabs, m, n, k, transA, transB, lda, ldb, n, 0.f, 1.f, nullptr, MC_NEURON_NONE, nullptr, 0, chunks,
-                           (long)m * n, S(s));
+                           (long)m * n, nullptr, nullptr, S(s));
         if (rc) return rc;
         // gemm_impl may round the chunk size up; recompute how many slabs were written
         int kChunk = (ceil_div(k, chunks) + 31) / 32 * 32;
@@ -370,7 +438,7 @@ static int gemm_entry(const char* who, const float* A, const float* B, float* C,
         return launch_status("mc_gemm(split-k reduce)");
     }
     return gemm_impl(A, B, C, m, n, k, transA, transB, lda, ldb, ldc, scaleTargets, scaleOutput, rowBias, neuron, mask, ldmask, 1, 0,
-                     S(s));
+                     bitsOut, bitsIn, S(s));
 }
 
 int mc_gemm(const float* A, const float* B, float* C, int m, int n, int k, int transA, int transB, int lda, int ldb,
@@ -386,6 +454,30 @@ int mc_gemm_relu_grad(const float* A, const float* B, float* C, int m, int n, in
     MC_REQUIRE(reluActs, "mc_gemm_relu_grad: null reluActs");
     return gemm_entry("mc_gemm_relu_grad", A, B, C, m, n, k, transA, transB, lda, ldb, ldc, scaleTargets, scaleOutput, nullptr,
                       MC_NEURON_NONE, reluActs, ldr, workspace, workspaceBytes, s);
+}
+
+size_t mc_relu_bits_words(int rows, int ld) { return rows > 0 && ld > 0 ? (size_t)((rows + 31) / 32) * ld : 0; }
+
+int mc_gemm_relu_bits(const float* A, const float* B, float* C, int m, int n, int k, int transA, int transB, int lda, int ldb, int ldc,
+                      const float* rowBias, unsigned* reluBits, mcStream_t s) {
+    MC_REQUIRE(reluBits, "mc_gemm_relu_bits: null reluBits");
+    MC_REQUIRE(!transA && !transB, "mc_gemm_relu_bits: only the forward orientation (transA = transB = 0) writes bit masks");
+    return gemm_entry("mc_gemm_relu_bits", A, B, C, m, n, k, transA, transB, lda, ldb, ldc, 0.f, 1.f, rowBias, MC_NEURON_RELU, nullptr, 0,
+                      nullptr, 0, s, reluBits, nullptr);
+}
+
+int mc_gemm_relu_grad_bits(const float* A, const float* B, float* C, int m, int n, int k, int transA, int transB, int lda, int ldb,
+                           int ldc, float scaleOutput, const unsigned* reluBits, mcStream_t s) {
+    MC_REQUIRE(reluBits, "mc_gemm_relu_grad_bits: null reluBits");
+    MC_REQUIRE(transA && !transB, "mc_gemm_relu_grad_bits: only the backward orientation (transA = 1, transB = 0) reads bit masks");
+    return gemm_entry("mc_gemm_relu_grad_bits", A, B, C, m, n, k, transA, transB, lda, ldb, ldc, 0.f, scaleOutput, nullptr, MC_NEURON_NONE,
+                      nullptr, 0, nullptr, 0, s, nullptr, reluBits);
+}
+
+int mc_relu_bits_from_acts(const float* acts, unsigned* reluBits, int rows, int cols, int ld, mcStream_t s) {
+    MC_REQUIRE(acts && reluBits && rows > 0 && cols > 0 && ld >= cols, "mc_relu_bits_from_acts: bad arguments");
+    hipLaunchKernelGGL(k_relu_bits_from_acts, dim3(grid_items((size_t)ceil_div(rows, 32) * cols)), dim3(TPB), 0, S(s), acts, reluBits, rows, cols, ld);
+    return launch_status("mc_relu_bits_from_acts");
 }
 
 size_t mc_conv_weight_grad_workspace_bytes(int numImages, int numImgColors, int numFilters, int filterSize, int numModules,

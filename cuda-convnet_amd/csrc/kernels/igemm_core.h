@@ -1,4 +1,7 @@
-// igemm.hip -- fp32-MFMA implicit-GEMM engine for gfx950 (MI355X).
+#pragma once
+// igemm_core.h -- fp32-MFMA implicit-GEMM engine for gfx950 (MI355X): the kernel template, its operand loaders and the
+// host-side launch / tile-choice helpers.  Included by igemm_{fwd,bwd,wgrad,gemm}.hip, one translation unit per family of
+// instantiations (they compile in parallel).
 //
 // One kernel template computes C(i,j) = sum_k A(i,k) * B(k,j) with both operands supplied
 // by "loaders" that know how to gather a (BK x ROWS) tile from the reference's
@@ -36,16 +39,23 @@
 #include "mc_common.h"
 
 #ifdef MC_STAMP   // diagnostic build only (tools/build_variant.sh stamp -DMC_STAMP): where do the K steps spend their cycles?
-__device__ unsigned long long g_stamp[8192 * 8];
-extern "C" int mc_debug_read_stamps(unsigned long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
-}
+static __device__ unsigned long long g_stamp[8192 * 8];   // one array per translation unit (no relocatable device code)
+#define MC_STAMP_API(tag)                                                                                      \
+    extern "C" int mc_debug_read_stamps_##tag(unsigned long long* out, int n) {                                \
+        return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), (size_t)n * 8, 0, hipMemcpyDeviceToHost);    \
+    }                                                                                                          \
+    extern "C" int mc_debug_clear_stamps_##tag(void) {                                                         \
+        static unsigned long long zeros[8192 * 8];                                                             \
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), zeros, sizeof(zeros), 0, hipMemcpyHostToDevice);    \
+    }
 #define STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define STAMP(var) do { } while (0)
+#define MC_STAMP_API(tag)
 #endif
 
 namespace mc {
+extern thread_local bool g_tuneInhibit;   // defined in igemm_fwd.hip; see set_tune_inhibit
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -95,7 +105,22 @@ struct Epi {
     int ldmask;
     unsigned cBytes;    // extent of one chunk's output in bytes: range of the store descriptor
     unsigned mBytes;    // extent of the mask in bytes
+    // relu masks as bits, one per output element, in the layout of the MFMA accumulators (mc_kernels.h, "relu bit masks"):
+    // a 32-bit word per (32-row block, column), word (i >> 5) * ldc + j; bit 16 * h + r <-> row (i & ~31) + (r & 3) + 8 * (r >> 2) + 4 * h,
+    // i.e. each lane's 16 accumulators of a 32x32 block are one 16-bit half word: no cross-lane traffic to write or to read.
+    unsigned* bitsOut;        // nullable: written by the epilogue, bit = (output > 0)
+    const unsigned* bitsIn;   // EPI_BITS kernels: outputs whose bit is clear are written as 0 (relu gradient)
+    unsigned wBytes;          // extent of the bit matrix in bytes
 };
+// Epilogue flavours (a template parameter: as run-time branches inside one kernel the variants that load cost every
+// instantiation 40-80 registers, i.e. a resident workgroup per CU):
+//   EPI_PLAIN  alpha * acc (+ bias) (relu) (+ bit-mask output); no loads.  The hot path of every product.
+//   EPI_SLOW   anything: scaleTargets != 0, float masks.  One element at a time, few registers, slow (200+ cycles per
+//              store instruction): accumulating calls and odd shapes only.
+//   EPI_BITS   EPI_PLAIN with the relu-gradient mask read as bits (dense products only).
+//   EPI_PLAIN_BITSOUT  EPI_PLAIN that also writes the bit mask (output > 0) of what it stores (relu forward products whose
+//              gradient mask a dense backward product reads).
+enum { EPI_PLAIN = 0, EPI_SLOW = 1, EPI_BITS = 2, EPI_PLAIN_BITSOUT = 3 };
 // (batch b of a batched launch writes columns [b * d.colB, b * d.colB + d.Ng) of C)
 
 // exact floor(a / d) for 0 <= a < 2^22 using a precomputed float reciprocal
@@ -410,8 +435,11 @@ __device__ __forceinline__ void lds_done_barrier() {
 // ---------------------------------------------------------------------------------
 // (Asking for more resident workgroups per CU through __launch_bounds__' second argument was measured: the
 // register cap spills in the k-contiguous loaders and no shape gets faster.)
-template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC, int NS>
+template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC, int NS, int EPI>
 __global__ void __launch_bounds__(2 * THREADS)
+#ifndef MC_NO_T51_CAP   // the 160-row tile sits 3-17 registers above 128 = two resident workgroups per CU: cap it (a few spills outside the K loop)
+__attribute__((amdgpu_waves_per_eu((MT == 5 && NT == 1) ? 4 : 1)))
+#endif
 mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     static_assert(WM * WN == 4, "4 consumer waves");
     static_assert(NS >= 2, "at least two tile register sets");
@@ -444,6 +472,11 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     const int nkTile = (kend - kbeg + BK - 1) / BK;   // K steps per tile, >= 1
     const int nk = nkTile * nTiles;                   // pipeline steps; barriers executed by every wave: 1 + nk
 
+#ifdef MC_ABL_STAGGER   // timing-only ablation: do the workgroups of a CU hurt each other by running in lockstep?
+    if (MC_ABL_STAGGER == 1 ? ((blockIdx.x >> 3) & 1) : (2 * blockIdx.x >= gridDim.x)) {
+        __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     if (threadIdx.x >= THREADS) {
         // ------------------------------ producer waves ------------------------------
         // Register ring of NS tile sets: tile u lives in set u % NS and goes to LDS stage u % 3.  Tiles 0
@@ -491,7 +524,7 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
             if (u < nk) fetch(as[u], bs[u], u);
         // per-row bias of this tile -> LDS (behind the three stages), so the epilogue does not wait on one global load
         // per output row; visible to the consumers through the first barrier
-        if (ep.bias && tid < BM) smem[3 * STAGE + tid] = (i0 + tid < d.Mg) ? ep.bias[i0 + tid + g * ep.rowG] : 0.f;
+        if (tid < BM) smem[3 * STAGE + tid] = (ep.bias && i0 + tid < d.Mg) ? ep.bias[i0 + tid + g * ep.rowG] : 0.f;
         commit(as[0], bs[0], 0);
         if (NS < nk) fetch(as[0], bs[0], NS);
         if (1 < nk) {
@@ -574,7 +607,12 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         for (int a = 0; a < MT; ++a) {
             const int row = (wm * MT + a) * 32 + l31;
             if (LA::KC) {
-                if (e == 0) {
+                if (MT >= 5) {   // tall wave tiles: two b64 reads per k8 group halve the fragment registers in flight
+                    if ((e & 1) == 0) {
+                        const float2 v = reinterpret_cast<const float2*>(cA)[((k8 * 2 + h) * LA::ROWSP + row) * 2 + (e >> 1)];
+                        af[s_][a] = v.x; af[s_ + 1][a] = v.y;
+                    }
+                } else if (e == 0) {
                     const float4 v = reinterpret_cast<const float4*>(cA)[(k8 * 2 + h) * LA::ROWSP + row];
                     af[s_][a] = v.x; af[s_ + 1][a] = v.y; af[s_ + 2][a] = v.z; af[s_ + 3][a] = v.w;
                 }
@@ -601,33 +639,110 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     // (ep.cBytes) and an element outside the product is stored at offset 0xFFFFFFFF, which the range check drops.
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(ep.C + q * ep.chunkStride, 0, ep.cBytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ep.mask ? ep.mask : ep.C), 0, ep.mask ? ep.mBytes : 0u, 0x00020000);
+    // EPI_PLAIN / EPI_BITS: the store is BATCHED -- per 32x32 block the byte offsets of 8 rows are formed, then 8 stores go
+    // out back to back; the bias comes from LDS as four b128 reads per block (a tile without bias reads zeros), relu is a
+    // select.  (One element at a time -- LDS bias read, wait, mask load, wait, store -- cost 200-500 cycles per store
+    // instruction: MC_STAMP showed 30-50 % of a consumer's cycles in the store of short-K products.)
+    // Bit masks: the relu-gradient mask of a block is ONE register per lane, the 16-bit half word of the lane's own 16
+    // accumulators, loaded at the top of the tile so that its latency hides under the K loop.  A relu epilogue writes
+    // the same layout: one 16-bit store per lane and block.
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(EPI == EPI_BITS ? ep.bitsIn : ep.bitsOut), 0,
+                                                                            (EPI == EPI_BITS || EPI == EPI_PLAIN_BITSOUT) ? ep.wBytes : 0u, 0x00020000);
+    unsigned mw[MT][NT];   // EPI_BITS: this lane's mask bits of the tile
+    (void)mw;
+    auto bits_off = [&](int a, int b, int j0) -> unsigned {   // byte offset of this lane's half word of block (a, b)
+        const int ib = i0 + (wm * MT + a) * 32, j = j0 + (wn * NT + b) * 32 + l31;
+        return ((ib < ilim) & (j < jlim)) ? (unsigned)((ib >> 5) * ep.ldc + j) * 4u + 2u * (unsigned)h : OOB;
+    };
+    auto load_mask_words = [&](int j0) {
+        if constexpr (EPI == EPI_BITS) {
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b) mw[a][b] = __builtin_amdgcn_raw_buffer_load_b16(rw, bits_off(a, b, j0), 0, 0);
+        }
+    };
     auto store_tile = [&](int j0) {
+#ifdef MC_ABL_NOSTORE   // timing-only ablation: keep the accumulators alive, store nothing in range
+        if (j0 >= 0) j0 = 0x3FFFFFFF;
+#endif
         // the row terms below do not change from tile to tile; an opaque copy of h keeps the compiler from
         // hoisting ~64 registers per 32-row block of them out of the tile loop (measured: spills in the 160-row tiles)
         int hh = h;
         asm volatile("" : "+v"(hh));
-#pragma unroll
-        for (int a = 0; a < MT; ++a) {
-#pragma unroll
-            for (int b = 0; b < NT; ++b) {
-                const int j = j0 + (wn * NT + b) * 32 + l31;
-                const bool jok = j < jlim;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rl = (wm * MT + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    const int i = i0 + rl;
-                    const bool ok = jok & (i < ilim);
-                    const int row = i + g * ep.rowG;
-                    const unsigned off = ok ? (unsigned)(row * ep.ldc + j + g * ep.colG) * 4u : OOB;
-                    float v = ep.alpha * acc[a][b][r];
-                    if (ep.beta != 0.f) v += ep.beta * __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rc, off, 0, 0));
-                    if (ep.bias) v += smem[3 * STAGE + rl];
-                    if (ep.act == MC_NEURON_RELU) v = v < 0.f ? 0.f : v;
-                    if (ep.mask) {
-                        const unsigned moff = ok ? (unsigned)(row * ep.ldmask + j + g * ep.colG) * 4u : OOB;
-                        if (!(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, moff, 0, 0)) > 0.f)) v = 0.f;
+        if constexpr (EPI == EPI_SLOW) {
+    #pragma unroll
+            for (int a = 0; a < MT; ++a) {
+    #pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    const int j = j0 + (wn * NT + b) * 32 + l31;
+                    const bool jok = j < jlim;
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = (wm * MT + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        const int i = i0 + rl;
+                        const bool ok = jok & (i < ilim);
+                        const int row = i + g * ep.rowG;
+                        const unsigned off = ok ? (unsigned)(row * ep.ldc + j + g * ep.colG) * 4u : OOB;
+                        float v = ep.alpha * acc[a][b][r];
+                        if (ep.beta != 0.f) v += ep.beta * __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rc, off, 0, 0));
+                        if (ep.bias) v += smem[3 * STAGE + rl];
+                        if (ep.act == MC_NEURON_RELU) v = v < 0.f ? 0.f : v;
+                        if (ep.mask) {
+                            const unsigned moff = ok ? (unsigned)(row * ep.ldmask + j + g * ep.colG) * 4u : OOB;
+                            if (!(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, moff, 0, 0)) > 0.f)) v = 0.f;
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, off, 0, 0);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, off, 0, 0);
+                }
+            }
+        } else {
+            const unsigned ldcB = (unsigned)ep.ldc * 4u;
+            const bool relu = ep.act == MC_NEURON_RELU;
+            constexpr bool WB = EPI == EPI_PLAIN_BITSOUT;
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                // this lane's 16 rows of block a: rl0 + (r & 3) + 8 * (r >> 2), taken four at a time (one b128 of bias each;
+                // the next group's bias is requested before this group's stores)
+                const int rl0 = (wm * MT + a) * 32 + 4 * hh;
+                const int iB = i0 + rl0;
+                const unsigned rowB = (unsigned)(iB + g * ep.rowG) * ldcB;
+                unsigned pb[NT];   // (output > 0) of this lane's 16 elements of block (a, b)
+#pragma unroll
+                for (int b = 0; b < NT; ++b) pb[b] = 0;
+                float4 bq = *reinterpret_cast<const float4*>(&smem[3 * STAGE + rl0]);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    __builtin_amdgcn_sched_barrier(0);   // one group at a time: hoisted, the loads and offsets of a whole tile are 40+ live registers
+                    float4 bn = bq;
+                    if (q4 < 3) bn = *reinterpret_cast<const float4*>(&smem[3 * STAGE + rl0 + 8 * (q4 + 1)]);
+                    const float bia[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) {
+                        const int j = j0 + (wn * NT + b) * 32 + l31;
+                        const bool jok = j < jlim;
+                        const unsigned colB = (unsigned)(j + g * ep.colG) * 4u;
+                        unsigned off[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int dr = 8 * q4 + e;
+                            off[e] = (jok & (iB + dr < ilim)) ? rowB + (unsigned)dr * ldcB + colB : OOB;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = 4 * q4 + e;
+                            float v = ep.alpha * acc[a][b][r] + bia[e];
+                            v = (relu & (v < 0.f)) ? 0.f : v;
+                            if constexpr (EPI == EPI_BITS) v = ((mw[a][b] >> r) & 1u) ? v : 0.f;
+                            if constexpr (WB) pb[b] |= (v > 0.f) ? (1u << r) : 0u;   // rows / columns outside the product: bits nobody reads
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, off[e], 0, 0);
+                        }
+                    }
+                    bq = bn;
+                }
+                if constexpr (WB) {
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)pb[b], rw, bits_off(a, b, j0), 0, 0);
                 }
             }
         }
@@ -637,8 +752,8 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
 #pragma unroll
     for (int s_ = 0; s_ < PF; ++s_) load_slab(smem, smem + LA::LDS_FLOATS, s_);
     int stage = 0;
-    unsigned long long c0 = 0, c1 = 0, c2 = 0, cStart = 0, accM = 0, accW = 0;
-    (void)c0; (void)c1; (void)c2; (void)cStart; (void)accM; (void)accW;
+    unsigned long long c0 = 0, c1 = 0, c2 = 0, cStart = 0, accM = 0, accW = 0, s0 = 0, s1 = 0, accS = 0;
+    (void)c0; (void)c1; (void)c2; (void)cStart; (void)accM; (void)accW; (void)s0; (void)s1; (void)accS;
     STAMP(cStart);
 #ifdef MC_STAMP
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
@@ -646,6 +761,7 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     // one trip per column tile of this worker; the accumulators are (re)defined at the top of the trip, so no
     // accumulator value is live around the outer loop
     for (int ct = blockIdx.x; ct < d.colTiles; ct += gridDim.x) {
+    load_mask_words(coff + col_block(ct) * BN);
 #pragma unroll
     for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -684,13 +800,18 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         stage = nstage;
     }
     // this tile's K loop is complete: store it while the producers run ahead into the next tile
+    STAMP(s0);
     store_tile(coff + col_block(ct) * BN);
+    STAMP(s1);
+#ifdef MC_STAMP
+    accS += s1 - s0;
+#endif
     }
 #ifdef MC_STAMP
     if (tid == 0) {
         const int blk = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
-        if (blk < 8192) { g_stamp[blk * 8 + 0] = c2 - cStart; g_stamp[blk * 8 + 1] = accM; g_stamp[blk * 8 + 2] = ((rt1 - rt0) << 32) | (accW & 0xFFFFFFFFull); g_stamp[blk * 8 + 3] = (unsigned long long)nk; }
+        if (blk < 8192) { g_stamp[blk * 8 + 0] = c2 - cStart; g_stamp[blk * 8 + 1] = accM; g_stamp[blk * 8 + 2] = ((rt1 - rt0) << 32) | (accW & 0xFFFFFFFFull); g_stamp[blk * 8 + 3] = (unsigned long long)nk | (accS << 32); }
     }
 #endif
 
@@ -699,7 +820,7 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
 // ---------------------------------------------------------------------------------
 // Host-side launch helpers
 // ---------------------------------------------------------------------------------
-template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC, int NS = MC_NS>
+template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC, int EPI, int NS = MC_NS>
 int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const ConvG& cg, const Dims& d0,
                const Epi& ep, int chunks, hipStream_t st) {
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
@@ -707,7 +828,7 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
     typedef Loader<BADDR, BN, BK, VEC> LB;
     constexpr size_t lds = (3 * (LA::LDS_FLOATS + LB::LDS_FLOATS) + BM) * sizeof(float);   // three stages + the tile's bias column
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = mc_igemm<AADDR, BADDR, MT, NT, WM, WN, BK, VEC, NS>;
+    auto kern = mc_igemm<AADDR, BADDR, MT, NT, WM, WN, BK, VEC, NS, EPI>;
     Dims d = d0;
     // per-device state of this instantiation (a function attribute belongs to the device's own code object)
     static std::atomic<unsigned long long> attrDone{0};
@@ -755,21 +876,29 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
 enum { T11, T21, T31, T51, T23, T32, T14, T24, NTILES };
 static const char* const kTileName[NTILES] = {"32x128", "64x128", "96x128", "160x128", "128x192", "192x128", "128x32", "128x64"};
 
-template <class AADDR, class BADDR, int BK, int VEC>
+template <class AADDR, class BADDR, int BK, int VEC, int EPI>
 int launch_tile(int tile, const typename AADDR::P& pa, const typename BADDR::P& pb, const ConvG& cg, const Dims& d, const Epi& ep,
                 int chunks, hipStream_t st) {
+    // the slow epilogue exists for three row heights only (any tile is correct for any shape): fewer instantiations
+    if constexpr (EPI == EPI_SLOW) tile = tile == T51 || tile == T32 ? T31 : tile == T23 ? T21 : tile;
     switch (tile) {
-        case T11: return launch_cfg<AADDR, BADDR, 1, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
-        case T21: return launch_cfg<AADDR, BADDR, 2, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
-        case T31: return launch_cfg<AADDR, BADDR, 3, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
-        case T51: return launch_cfg<AADDR, BADDR, 5, 1, 1, 4, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
-        case T23: return launch_cfg<AADDR, BADDR, 2, 3, 2, 2, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+        case T11: return launch_cfg<AADDR, BADDR, 1, 1, 1, 4, BK, VEC, EPI>(pa, pb, cg, d, ep, chunks, st);
+        case T21: return launch_cfg<AADDR, BADDR, 2, 1, 1, 4, BK, VEC, EPI>(pa, pb, cg, d, ep, chunks, st);
         // four waves stacked over ONE 32-column strip: products with at most 64 columns (weight gradients of layers with
         // 32 / 64 filters) would otherwise run 128-column tiles that are 3/4 or 1/2 padding
-        case T14: return launch_cfg<AADDR, BADDR, 1, 1, 4, 1, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
-        case T24: return launch_cfg<AADDR, BADDR, 2, 1, 2, 2, BK, VEC>(pa, pb, cg, d, ep, chunks, st);   // 2x2 waves, 64 columns
-        default:  return launch_cfg<AADDR, BADDR, 3, 2, 2, 2, BK, VEC>(pa, pb, cg, d, ep, chunks, st);
+        case T14: return launch_cfg<AADDR, BADDR, 1, 1, 4, 1, BK, VEC, EPI>(pa, pb, cg, d, ep, chunks, st);
+        case T24: return launch_cfg<AADDR, BADDR, 2, 1, 2, 2, BK, VEC, EPI>(pa, pb, cg, d, ep, chunks, st);   // 2x2 waves, 64 columns
+        default: break;
     }
+    if constexpr (EPI != EPI_SLOW) {
+        switch (tile) {
+            case T51: return launch_cfg<AADDR, BADDR, 5, 1, 1, 4, BK, VEC, EPI>(pa, pb, cg, d, ep, chunks, st);
+            case T23: return launch_cfg<AADDR, BADDR, 2, 3, 2, 2, BK, VEC, EPI>(pa, pb, cg, d, ep, chunks, st);
+            case T32: return launch_cfg<AADDR, BADDR, 3, 2, 2, 2, BK, VEC, EPI>(pa, pb, cg, d, ep, chunks, st);
+            default: break;
+        }
+    }
+    return launch_cfg<AADDR, BADDR, 3, 1, 1, 4, BK, VEC, EPI>(pa, pb, cg, d, ep, chunks, st);
 }
 
 // Static rule (measured on MI355X, tools/tile_sweep.py over the NIN shapes): 128-column tiles (one 32-column
@@ -798,22 +927,21 @@ struct TuneKey {
 };
 static std::map<TuneKey, int> g_tuned;
 static std::mutex g_tuneMu;
-static thread_local bool g_tuneInhibit = false;
 
-template <class AADDR, class BADDR, int BK, int VEC>
-int launch_rows_cols(const typename AADDR::P& pa, const typename BADDR::P& pb, const ConvG& cg, const Dims& d,
+template <class AADDR, class BADDR, int BK, int VEC, int EPI>
+int launch_rows_cols_epi(const typename AADDR::P& pa, const typename BADDR::P& pb, const ConvG& cg, const Dims& d,
                      const Epi& ep, int chunks, hipStream_t st) {
     // tuning knob (benchmarks only): MC_IGEMM_TILE="MT,NT" forces the wave tile
     static const char* forced = getenv("MC_IGEMM_TILE");
     if (forced && forced[0] && forced[1] == ',') {
         static const int map[8][3] = {{1, 1, T11}, {2, 1, T21}, {3, 1, T31}, {5, 1, T51}, {2, 3, T23}, {3, 2, T32}, {4, 0, T14}, {4, 1, T24}};
         for (auto& m : map)
-            if (forced[0] - '0' == m[0] && forced[2] - '0' == m[1]) return launch_tile<AADDR, BADDR, BK, VEC>(m[2], pa, pb, cg, d, ep, chunks, st);
+            if (forced[0] - '0' == m[0] && forced[2] - '0' == m[1]) return launch_tile<AADDR, BADDR, BK, VEC, EPI>(m[2], pa, pb, cg, d, ep, chunks, st);
     }
     const int rule = heuristic_tile(d, chunks);
     static const char* at = getenv("MC_IGEMM_AUTOTUNE");
     static const int mode = at ? atoi(at) : 1;
-    if (mode == 0) return launch_tile<AADDR, BADDR, BK, VEC>(rule, pa, pb, cg, d, ep, chunks, st);
+    if (mode == 0) return launch_tile<AADDR, BADDR, BK, VEC, EPI>(rule, pa, pb, cg, d, ep, chunks, st);
 
     static char kindTag;
     int dev = 0;
@@ -821,20 +949,20 @@ int launch_rows_cols(const typename AADDR::P& pa, const typename BADDR::P& pb, c
     TuneKey key;
     key.kind = &kindTag;
     const int vals[20] = {d.Mg, d.Ng, d.Kg, d.kChunk, d.groups, d.batches, d.colB, chunks, cg.N, cg.H, cg.W, cg.fc, cg.fs, cg.pad,
-                          cg.stride, cg.MY, cg.MX, cg.F, cg.local, dev};
+                          cg.stride, cg.MY, cg.MX, cg.F, cg.local, dev * 4 + EPI};
     memcpy(key.v, vals, sizeof(vals));
     {
         std::lock_guard<std::mutex> lk(g_tuneMu);
         auto it = g_tuned.find(key);
-        if (it != g_tuned.end()) return launch_tile<AADDR, BADDR, BK, VEC>(it->second, pa, pb, cg, d, ep, chunks, st);
+        if (it != g_tuned.end()) return launch_tile<AADDR, BADDR, BK, VEC, EPI>(it->second, pa, pb, cg, d, ep, chunks, st);
     }
     // an accumulating call (scaleTargets != 0) is not idempotent: serve it by the rule and let a later plain call tune;
     // so is a call from an entry point that must not create events or block (mc_conv_weight_grad_noalloc)
-    if (ep.beta != 0.f || g_tuneInhibit) return launch_tile<AADDR, BADDR, BK, VEC>(rule, pa, pb, cg, d, ep, chunks, st);
+    if (EPI == EPI_SLOW || ep.beta != 0.f || g_tuneInhibit) return launch_tile<AADDR, BADDR, BK, VEC, EPI>(rule, pa, pb, cg, d, ep, chunks, st);
 
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
-        return launch_tile<AADDR, BADDR, BK, VEC>(rule, pa, pb, cg, d, ep, chunks, st);
+        return launch_tile<AADDR, BADDR, BK, VEC, EPI>(rule, pa, pb, cg, d, ep, chunks, st);
     int best = rule;
     float bestMs = 1e30f, ms[NTILES];
     for (int t = 0; t < NTILES; ++t) {
@@ -843,10 +971,10 @@ int launch_rows_cols(const typename AADDR::P& pa, const typename BADDR::P& pb, c
         static const int rowsOf[NTILES] = {32, 64, 96, 160, 128, 192, 128, 128};
         if (t != rule && (long)ceil_div(d.Mg, rowsOf[t]) * rowsOf[t] > 4L * ((d.Mg + 31) / 32 * 32)) continue;
         if ((t == T14 || t == T24) && d.Ng > 64) continue;   // the narrow tile only where 128 columns are mostly padding
-        int rc = launch_tile<AADDR, BADDR, BK, VEC>(t, pa, pb, cg, d, ep, chunks, st);   // warm (and validates the launch)
+        int rc = launch_tile<AADDR, BADDR, BK, VEC, EPI>(t, pa, pb, cg, d, ep, chunks, st);   // warm (and validates the launch)
         if (rc != MC_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
         (void)hipEventRecord(e0, st);
-        for (int r = 0; r < 2; ++r) (void)launch_tile<AADDR, BADDR, BK, VEC>(t, pa, pb, cg, d, ep, chunks, st);
+        for (int r = 0; r < 2; ++r) (void)launch_tile<AADDR, BADDR, BK, VEC, EPI>(t, pa, pb, cg, d, ep, chunks, st);
         (void)hipEventRecord(e1, st);
         if (hipEventSynchronize(e1) != hipSuccess) continue;
         float el = 0.f;
@@ -869,6 +997,28 @@ int launch_rows_cols(const typename AADDR::P& pa, const typename BADDR::P& pb, c
         g_tuned[key] = best;
     }
     return MC_OK;   // the timed launches already produced the result (identical for every tile)
+}
+
+// Picks the epilogue flavour.  BITS / BOUT: whether this call site instantiates the kernels that read / write relu bit masks
+// (dense backward products read them; dense and conv forward products write them).
+template <class AADDR, class BADDR, int BK, int VEC, bool BITS = false, bool BOUT = false>
+int launch_rows_cols(const typename AADDR::P& pa, const typename BADDR::P& pb, const ConvG& cg, const Dims& d,
+                     const Epi& ep, int chunks, hipStream_t st) {
+    const bool plain = ep.beta == 0.f && !ep.mask;
+    if (ep.bitsIn || ep.bitsOut) {
+        if (!plain || d.groups != 1 || d.batches != 1 || (ep.bitsIn && ep.bitsOut) || ep.chunkStride != 0) {
+            set_error("mc_igemm: relu bit masks need scaleTargets == 0, one group, no float mask and an unsplit product");
+            return MC_EINVAL;
+        }
+        if constexpr (BITS)
+            if (ep.bitsIn) return launch_rows_cols_epi<AADDR, BADDR, BK, VEC, EPI_BITS>(pa, pb, cg, d, ep, chunks, st);
+        if constexpr (BOUT)
+            if (ep.bitsOut) return launch_rows_cols_epi<AADDR, BADDR, BK, VEC, EPI_PLAIN_BITSOUT>(pa, pb, cg, d, ep, chunks, st);
+        set_error("mc_igemm: relu bit masks are not available for this product");
+        return MC_EINVAL;
+    }
+    if (!plain) return launch_rows_cols_epi<AADDR, BADDR, BK, VEC, EPI_SLOW>(pa, pb, cg, d, ep, chunks, st);
+    return launch_rows_cols_epi<AADDR, BADDR, BK, VEC, EPI_PLAIN>(pa, pb, cg, d, ep, chunks, st);
 }
 
 inline float finv(int d) { return 1.0f / (float)d; }
@@ -895,173 +1045,4 @@ int make_convg(ConvG& cg, int N, int C, int H, int W, int F, int fs, int pad, in
 }
 
 }  // namespace
-
-// While set (per host thread), a shape that has not been tuned yet runs the static rule's tile instead of the timed trial.
-void set_tune_inhibit(bool on) { g_tuneInhibit = on; }
-
-// =================================================================================
-// conv forward: C[f][(m,n)] ; Mg = F/groups, Ng = M*N, Kg = fc*fp
-// =================================================================================
-int conv_filter_acts_impl(const float* images, const float* filters, float* targets, const float* biases, int neuron,
-                          int N, int C, int H, int W, int F, int fs, int pad, int stride, int MY, int MX, int groups,
-                          int local, float scaleTargets, float scaleOutput, float* slabs, int kChunk, hipStream_t st) {
-    ConvG cg;
-    int rc = make_convg(cg, N, C, H, W, F, fs, pad, stride, MY, MX, groups, local, local ? "localFilterActs" : "convFilterActs");
-    if (rc) return rc;
-    int chunks = 1;
-    // shared filters: one product over all M*N columns.  Unshared (filter_acts.cu conv=false): M products in one
-    // launch, batch = module, each over its own N columns with its own filter bank W[m].
-    Dims d{cg.fpg, local ? N : cg.M * N, cg.fc * cg.fp, cg.fc * cg.fp, groups, 0, 0, local ? cg.M : 1, local ? N : 0};
-    Epi ep{targets, cg.M * N, cg.fpg, 0, 0, scaleOutput, scaleTargets, biases, neuron, nullptr, 0, (unsigned)((size_t)F * cg.M * N * 4), 0};
-    if (slabs && kChunk > 0 && !local) {   // split K: every chunk writes a plain slab, the caller reduces and applies the epilogue
-        d.kChunk = kChunk;
-        chunks = ceil_div(d.Kg, kChunk);
-        ep = Epi{slabs, cg.M * N, cg.fpg, 0, (long)F * cg.M * N, 1.f, 0.f, nullptr, MC_NEURON_NONE, nullptr, 0, (unsigned)((size_t)F * cg.M * N * 4), 0};
-    }
-    MatP pa{filters, F, cg.fpg, cg.fpg, (unsigned)((size_t)(local ? cg.M : 1) * cg.fc * cg.fp * F * 4), local ? cg.fc * cg.fp * F : 0};  // filters[k*F + g*fpg + f]
-    ConvP pb{images, cg.M * N, (unsigned)((size_t)C * H * W * N * 4)};
-    const bool vec = (N % 4 == 0) && (cg.fpg % 4 == 0) && (F % 4 == 0) && aligned16(images) && aligned16(filters);
-    if (vec) return launch_rows_cols<MatNatAddr, PatchNatAddr, MC_BK, 4>(pa, pb, cg, d, ep, chunks, st);
-    return launch_rows_cols<MatNatAddr, PatchNatAddr, MC_BK, 1>(pa, pb, cg, d, ep, chunks, st);
-}
-
-// =================================================================================
-// conv bwd-data: C[c][(px,n)] ; Mg = fc, Ng = H*W*N, Kg = fp*fpg
-// =================================================================================
-int conv_img_acts_impl(const float* hidActs, const float* filters, float* targets, int N, int C, int H, int W, int F,
-                       int fs, int pad, int stride, int MY, int MX, int groups, int local, float scaleTargets,
-                       float scaleOutput, float* slabs, int kChunk, hipStream_t st) {
-    ConvG cg;
-    int rc = make_convg(cg, N, C, H, W, F, fs, pad, stride, MY, MX, groups, local, local ? "localImgActs" : "convImgActs");
-    if (rc) return rc;
-    int chunks = 1;
-    // unshared (img_acts.cu conv=false): one product per image pixel (batch = pixel), whose A operand gathers, tap
-    // by tap, the filter bank of the module that sees the pixel at that tap (FiltTAddr)
-    Dims d{cg.fc, local ? N : H * W * N, cg.fp * cg.fpg, cg.fp * cg.fpg, groups, 0, 0, local ? H * W : 1, local ? N : 0};
-    Epi ep{targets, H * W * N, cg.fc, 0, 0, scaleOutput, scaleTargets, nullptr, MC_NEURON_NONE, nullptr, 0, (unsigned)((size_t)C * H * W * N * 4), 0};
-    if (slabs && kChunk > 0 && !local) {
-        d.kChunk = kChunk;
-        chunks = ceil_div(d.Kg, kChunk);
-        ep = Epi{slabs, H * W * N, cg.fc, 0, (long)C * H * W * N, 1.f, 0.f, nullptr, MC_NEURON_NONE, nullptr, 0, (unsigned)((size_t)C * H * W * N * 4), 0};
-    }
-    ConvP pa{filters, cg.fc, (unsigned)((size_t)(local ? cg.M : 1) * cg.fc * cg.fp * F * 4)};
-    ConvP pb{hidActs, H * W * N, (unsigned)((size_t)F * cg.M * N * 4)};
-    // group offset of the A operand rows: channel c of group g uses filter rows (cl*fp+p), columns g*fpg+fl
-    const bool vec = (N % 4 == 0) && (cg.fpg % 4 == 0) && (F % 4 == 0) && aligned16(hidActs) && aligned16(filters);
-    if (stride == 1 && groups == 1 && !local) {
-        // with one group the transposed-filter operand is a plain k-contiguous matrix: row c, k = p*F + f at c*fp*F + k
-        MatP pm{filters, cg.fp * F, cg.fc, 0, pa.bytes, 0};
-        if (vec) return launch_rows_cols<MatKcAddr, HidNatS1Addr, MC_BK, 4>(pm, pb, cg, d, ep, chunks, st);
-        return launch_rows_cols<MatKcAddr, HidNatS1Addr, MC_BK, 1>(pm, pb, cg, d, ep, chunks, st);
-    }
-    if (vec) return launch_rows_cols<FiltTAddr, HidNatAddr, MC_BK, 4>(pa, pb, cg, d, ep, chunks, st);
-    return launch_rows_cols<FiltTAddr, HidNatAddr, MC_BK, 1>(pa, pb, cg, d, ep, chunks, st);
-}
-
-// =================================================================================
-// conv bwd-weights: C[q][(c,p)][f] ; Mg = fc*fp, Ng = fpg, Kg = M*N, chunk = partialSum*N
-// =================================================================================
-int conv_weight_acts_impl(const float* images, const float* hidActs, float* targets, int N, int C, int H, int W, int F,
-                          int fs, int pad, int stride, int MY, int MX, int groups, int partialSum, int kChunk, float scaleTargets,
-                          float scaleOutput, hipStream_t st) {
-    ConvG cg;
-    int rc = make_convg(cg, N, C, H, W, F, fs, pad, stride, MY, MX, groups, 0, "convWeightActs");
-    if (rc) return rc;
-    cg.kcUniform = (N % MC_BK_KC == 0) ? 1 : 0;   // chunks and tiles start at multiples of BK: a tile stays inside one module
-    int chunks;
-    if (kChunk > 0) {   // module-unaligned chunks of the (module, image) axis (mc_conv_weight_grad)
-        MC_REQUIRE(kChunk % MC_BK_KC == 0, "convWeightActs: k chunk (%d) must be a multiple of %d", kChunk, MC_BK_KC);
-        chunks = ceil_div((long)cg.M * N, kChunk);
-    } else {
-        if (partialSum <= 0) partialSum = cg.M;
-        MC_REQUIRE(cg.M % partialSum == 0, "convWeightActs: partialSum (%d) must divide numModules (%d)", partialSum, cg.M);
-        chunks = cg.M / partialSum;
-        kChunk = partialSum * N;
-    }
-    Dims d{cg.fc * cg.fp, cg.fpg, cg.M * N, kChunk, groups, 0, 0, 1, 0};
-    Epi ep{targets, F, 0, cg.fpg, (long)cg.fc * cg.fp * F, scaleOutput, scaleTargets, nullptr, MC_NEURON_NONE, nullptr, 0, (unsigned)((size_t)cg.fc * cg.fp * F * 4), 0};
-    ConvP pa{images, cg.fc * cg.fp, (unsigned)((size_t)C * H * W * N * 4)};
-    MatP pb{hidActs, cg.M * N, cg.fpg, cg.fpg * cg.M * N, (unsigned)((size_t)F * cg.M * N * 4), 0};  // hid[(g*fpg+f)*M*N + k]
-    const bool vec = (N % 4 == 0) && aligned16(images) && aligned16(hidActs);
-    if (vec) return launch_rows_cols<PatchKcAddr, MatKcAddr, MC_BK_KC, 4>(pa, pb, cg, d, ep, chunks, st);
-    return launch_rows_cols<PatchKcAddr, MatKcAddr, MC_BK_KC, 1>(pa, pb, cg, d, ep, chunks, st);
-}
-
-// K split for the forward / backward-data products of layers with few columns (NIN conv3: 64 modules x 128 images):
-// with 96x128 tiles the grid would cover half the device, so K is cut into as many chunks as bring it to about one
-// workgroup per CU (at most 8, each >= 512 long, a multiple of 32); slabs + a fixed-order reduction as for the
-// weight gradients.  A pure function of the shape and the CU count.  Returns the chunk count (1 = no split).
-int conv_split_plan(int rows, long cols, int K, int groups, int* kChunkOut) {
-    const long tiles = (long)ceil_div(rows, 96) * ceil_div(cols, 128) * groups;
-    long chunks = num_cus() / tiles;
-    *kChunkOut = 0;
-    if (chunks < 2 || K < 512) return 1;
-    if (chunks > 8) chunks = 8;
-    long kc = (ceil_div(K, chunks) + 31) / 32 * 32;
-    const long kcMin = K >= 1024 ? 512 : 256;   // mid-size K (layers-80sec conv3 forward: 800 on 64 tiles) splits into shorter chunks
-    if (kc < kcMin) kc = kcMin;
-    if (kc >= K) return 1;
-    *kChunkOut = (int)kc;
-    return ceil_div(K, kc);
-}
-
-// Chunking of the (module, image) axis for mc_conv_weight_grad: as many chunks as keep about one workgroup per CU
-// (the k-contiguous tiles need ~80-120 KB of LDS, one workgroup per CU; a grid of 2.4 "rounds" costs 3), each chunk
-// a multiple of the K tile and at least 256 long.  A pure function of the shape and the CU count: the chunk count
-// fixes the order of the sum, so it must not depend on timing.
-int conv_weight_grad_plan(int N, int C, int F, int fs, int M, int groups, int* kChunkOut) {
-    const int rows = (C / groups) * fs * fs, fpg = F / groups;
-    const long K = (long)M * N;
-    Dims d{rows, fpg, (int)K, (int)K, groups, 0, 0, 1, 0};
-    static const int rowsOf[NTILES] = {32, 64, 96, 160, 128, 192, 128, 128}, colsOf[NTILES] = {128, 128, 128, 128, 192, 128, 32, 64};
-    // the tile the static rule would take for a grid that fills the device
-    const int t = heuristic_tile(d, ceil_div(num_cus(), (long)ceil_div(rows, 128) * ceil_div(fpg, 128) * groups));
-    const long tiles = (long)ceil_div(rows, rowsOf[t]) * ceil_div(fpg, colsOf[t]) * groups;
-    long chunks = num_cus() / tiles;
-    if (chunks < 1) chunks = 1;
-    long kc = (ceil_div(K, chunks) + MC_BK_KC - 1) / MC_BK_KC * MC_BK_KC;
-    if (kc < 256) kc = 256;
-    if (kc > K) kc = (K + MC_BK_KC - 1) / MC_BK_KC * MC_BK_KC;
-    *kChunkOut = (int)kc;
-    return ceil_div(K, kc);
-}
-
-// =================================================================================
-// dense: C(m,n) = beta*C + alpha*op(A)*op(B)
-// =================================================================================
-int gemm_impl(const float* A, const float* B, float* Cm, int m, int n, int k, int transA, int transB, int lda, int ldb,
-              int ldc, float beta, float alpha, const float* rowBias, int neuron, const float* mask, int ldmask, int chunks,
-              long chunkStride, hipStream_t st) {
-    ConvG cg{};
-    int kChunk = k;
-    if (chunks > 1) {
-        kChunk = ceil_div(k, chunks);
-        kChunk = (kChunk + 31) / 32 * 32;
-        chunks = ceil_div(k, kChunk);
-    }
-    Dims d{m, n, k, kChunk, 1, 0, 0, 1, 0};
-    Epi ep{Cm, ldc, 0, 0, chunkStride, alpha, beta, rowBias, neuron, mask, ldmask, (unsigned)(((size_t)(m - 1) * ldc + n) * 4),
-           mask ? (unsigned)(((size_t)(m - 1) * ldmask + n) * 4) : 0u};
-    // operand extents in bytes: (rows - 1) * ld + row length
-    const size_t ea = transA ? (size_t)(k - 1) * lda + m : (size_t)(m - 1) * lda + k;
-    const size_t eb = transB ? (size_t)(n - 1) * ldb + k : (size_t)(k - 1) * ldb + n;
-    MatP pa{A, lda, m, 0, (unsigned)(ea * 4), 0};
-    MatP pb{B, ldb, n, 0, (unsigned)(eb * 4), 0};
-    const bool al = aligned16(A) && aligned16(B) && lda % 4 == 0 && ldb % 4 == 0;
-    // vector loads need the contiguous extent of each operand to be a multiple of 4
-    const bool va = transA ? (m % 4 == 0) : (k % 4 == 0);
-    const bool vb = transB ? (k % 4 == 0) : (n % 4 == 0);
-    const bool vec = al && va && vb;
-#define MC_GEMM_CASE(AA, BB)                                                              \
-    (vec ? launch_rows_cols<AA, BB, MC_BK, 4>(pa, pb, cg, d, ep, chunks, st)                 \
-         : launch_rows_cols<AA, BB, MC_BK, 1>(pa, pb, cg, d, ep, chunks, st))
-    if (transA && !transB) return MC_GEMM_CASE(MatNatAddr, MatNatAddr);
-    if (!transA && !transB) return MC_GEMM_CASE(MatKcAddr, MatNatAddr);
-    if (!transA && transB)
-        return vec ? launch_rows_cols<MatKcAddr, MatKcAddr, MC_BK_KC, 4>(pa, pb, cg, d, ep, chunks, st)
-                   : launch_rows_cols<MatKcAddr, MatKcAddr, MC_BK_KC, 1>(pa, pb, cg, d, ep, chunks, st);
-    return MC_GEMM_CASE(MatNatAddr, MatKcAddr);
-#undef MC_GEMM_CASE
-}
-
 }  // namespace mc

@@ -157,6 +157,35 @@ int mc_gemm_relu_grad(const float* A, const float* B, float* C, int m, int n, in
                       const float* reluActs, int ldr, void* workspace, size_t workspaceBytes,
                       mcStream_t stream);
 
+/* ---------------- relu bit masks ----------------
+ * The gradient of a relu needs only (output > 0).  A forward product with a fused relu can write that as ONE BIT per
+ * element next to its output, and the backward product of the layer above reads the bits instead of the float
+ * activation (NIN cccp1 backward: 3 MB instead of 100 MB).  No counterpart in the reference, which keeps the
+ * activation for `actGrad * (act > 0)` (Kernel/include/layers/neuron.cuh:173-178).
+ * Layout (chosen so that the MFMA accumulator layout writes and reads it with no cross-lane traffic): for a
+ * (rows, cols) matrix with row stride ld, one 32-bit word per (32-row block, column): word (i >> 5) * ld + j; inside
+ * the word, bit p = 16 * h + r (h = 0..1, r = 0..15) stands for row (i & ~31) + (r & 3) + 8 * (r >> 2) + 4 * h.
+ * mc_relu_bits_words(rows, ld) words must be allocated.  Bits of rows >= rows are unspecified.
+ *   mc_conv_filter_acts_relu_bits  mc_conv_filter_acts_fused with neuron = relu, one group, scaleTargets = 0,
+ *                                  scaleOutput = 1, that also writes the bits of its output (ld = modules * numImages)
+ *   mc_gemm_relu_bits              mc_gemm (transA = transB = 0, scaleTargets = 0, scaleOutput = 1, relu) likewise (ld = ldc)
+ *   mc_gemm_relu_grad_bits         mc_gemm_relu_grad (transA = 1, transB = 0, scaleTargets = 0) with the mask given as bits (ld = ldc)
+ *   mc_relu_bits_from_acts         the bits of an activation matrix that is already in memory */
+size_t mc_relu_bits_words(int rows, int ld);
+int mc_conv_filter_acts_relu_bits(const float* images, const float* filters, float* targets,
+                                  const float* biases, unsigned* reluBits, int numImages, int numImgColors,
+                                  int imgSizeY, int imgSizeX, int numFilters, int filterSize,
+                                  int paddingStart, int moduleStride, int numModulesY, int numModulesX,
+                                  mcStream_t stream);
+int mc_gemm_relu_bits(const float* A, const float* B, float* C, int m, int n, int k, int transA,
+                      int transB, int lda, int ldb, int ldc, const float* rowBias, unsigned* reluBits,
+                      mcStream_t stream);
+int mc_gemm_relu_grad_bits(const float* A, const float* B, float* C, int m, int n, int k, int transA,
+                           int transB, int lda, int ldb, int ldc, float scaleOutput,
+                           const unsigned* reluBits, mcStream_t stream);
+int mc_relu_bits_from_acts(const float* acts, unsigned* reluBits, int rows, int cols, int ld,
+                           mcStream_t stream);
+
 /* ---------------- pooling ----------------
  * convLocalPool<MaxPooler|AvgPooler> (Kernel/include/conv/conv_util.cuh:335-524),
  * convLocalMaxUndo (Kernel/src/conv/conv_util.cu:1879-1968),

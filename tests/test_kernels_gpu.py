@@ -504,3 +504,77 @@ def test_conv_weight_grad_free_chunking(N, C, H, fs, F, pad, stride, groups):
         outs.append(host(dw))
     assert relerr(outs[0], 0.5 * prev + 0.01 * expw) < TOL
     assert np.array_equal(outs[0], outs[1])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# relu bit masks (include/mc_kernels.h "relu bit masks"): written by forward products, read by backward products
+# ---------------------------------------------------------------------------------------------------------
+def _decode_relu_bits(words, rows):
+    """(ceil(rows/32), cols) uint32 words -> (rows, cols) bool, following the documented layout."""
+    out = np.zeros((rows, words.shape[1]), dtype=bool)
+    for p in range(32):
+        h, r = p >> 4, p & 15
+        ro = (r & 3) + 8 * (r >> 2) + 4 * h
+        for rb in range(words.shape[0]):
+            i = rb * 32 + ro
+            if i < rows:
+                out[i] = (words[rb] >> np.uint32(p)) & np.uint32(1)
+    return out
+
+
+def _bits_buffer(m, rows, ld):
+    import torch
+    n = m.lib().mc_relu_bits_words(rows, ld)
+    assert n == ((rows + 31) // 32) * ld
+    return torch.full((n,), -1, dtype=torch.int32, device="cuda")   # poisoned: every valid word must be written
+
+
+@pytest.mark.parametrize("mm,nn,kk", [(160, 4096, 192), (96, 2048, 160), (10, 8192, 192), (192, 1000, 192), (70, 333, 50)])
+def test_gemm_relu_bits_forward_and_backward(mm, nn, kk):
+    m = mc()
+    rng = np.random.default_rng(91)
+    W = rng.standard_normal((mm, kk)).astype(np.float32)
+    x = rng.standard_normal((kk, nn)).astype(np.float32)
+    b = rng.standard_normal((mm,)).astype(np.float32)
+    dW, dx, db = dev(W), dev(x), dev(b)
+    ref = nans(mm, nn)
+    m.call("mc_gemm", ptr(dW), ptr(dx), ptr(ref), mm, nn, kk, 0, 0, kk, nn, nn, 0.0, 1.0, ptr(db), m.NEURON_RELU, None, 0, None)
+    out = nans(mm, nn)
+    bits = _bits_buffer(m, mm, nn)
+    m.call("mc_gemm_relu_bits", ptr(dW), ptr(dx), ptr(out), mm, nn, kk, 0, 0, kk, nn, nn, ptr(db), ptr(bits), None)
+    y = host(out)
+    assert np.array_equal(y, host(ref))
+    words = host(bits).view(np.uint32).reshape(-1, nn)
+    assert np.array_equal(_decode_relu_bits(words, mm), y > 0)
+    # bits rebuilt from the stored activation are the same words (valid rows)
+    bits2 = _bits_buffer(m, mm, nn)
+    m.call("mc_relu_bits_from_acts", ptr(out), ptr(bits2), mm, nn, nn, None)
+    assert np.array_equal(_decode_relu_bits(host(bits2).view(np.uint32).reshape(-1, nn), mm), y > 0)
+    # backward through the layer above: dIn(mm, nn) = V^T(mm, oo) * g(oo, nn), masked by this relu
+    oo = 96
+    V = dev(rng.standard_normal((oo, mm)))
+    g = dev(rng.standard_normal((oo, nn)))
+    a, c = nans(mm, nn), nans(mm, nn)
+    m.call("mc_gemm_relu_grad", ptr(V), ptr(g), ptr(a), mm, nn, oo, 1, 0, mm, nn, nn, 0.0, 0.5, ptr(out), nn, None, 0, None)
+    m.call("mc_gemm_relu_grad_bits", ptr(V), ptr(g), ptr(c), mm, nn, oo, 1, 0, mm, nn, nn, 0.5, ptr(bits), None)
+    assert np.array_equal(host(a), host(c))
+    exp = 0.5 * (host(V).astype(np.float64).T @ host(g).astype(np.float64)) * (y > 0)
+    assert relerr(host(c), exp) < TOL
+
+
+@pytest.mark.parametrize("N,C,H,fs,F,pad", [(128, 3, 32, 5, 192, 2), (64, 192, 8, 3, 192, 1), (16, 32, 8, 5, 64, 2), (6, 4, 7, 3, 10, 1)])
+def test_conv_relu_bits(N, C, H, fs, F, pad):
+    """conv + bias + relu + bit mask (the second shape takes the split-K path, whose reduction writes the bits)."""
+    m = mc()
+    rng = np.random.default_rng(92)
+    M = _modules(H, fs, pad, 1)
+    geo = (N, C, H, H, F, fs, -pad, 1, M, M)
+    img, W, b = dev(rng.standard_normal((C * H * H, N))), dev(rng.standard_normal((C * fs * fs, F))), dev(rng.standard_normal((F,)))
+    ref, out = nans(F * M * M, N), nans(F * M * M, N)
+    m.call("mc_conv_filter_acts_fused", ptr(img), ptr(W), ptr(ref), ptr(b), m.NEURON_RELU, *geo, 1, 0.0, 1.0, None)
+    bits = _bits_buffer(m, F, M * M * N)
+    m.call("mc_conv_filter_acts_relu_bits", ptr(img), ptr(W), ptr(out), ptr(b), ptr(bits), *geo, None)
+    y = host(out)
+    assert np.array_equal(y, host(ref))
+    words = host(bits).view(np.uint32).reshape(-1, M * M * N)
+    assert np.array_equal(_decode_relu_bits(words, F), y.reshape(F, M * M * N) > 0)

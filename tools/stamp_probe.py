@@ -1,48 +1,48 @@
-"""Diagnostic (MC_STAMP build): per-K-step cycle shares of consumer wave 0 and producer wave 4.
-   MC_KERNELS_LIB=build/variants/libmck_stamp.so python tools/stamp_probe.py"""
+"""Diagnostic (MC_STAMP build): per-K-step cycle shares of consumer wave 0 and producer wave 4, and the cycles a consumer
+spends storing its tiles.   MC_KERNELS_LIB=build/variants/libmck_stamp.so python tools/stamp_probe.py [conv|gemm]"""
 import os, sys, ctypes
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cuda-convnet_amd"))
 import numpy as np, torch
 import mckernels as m
 m._LIB_PATH = os.path.abspath(os.environ["MC_KERNELS_LIB"])
 R = lambda *s: torch.randn(*s, device="cuda"); P = lambda t: t.data_ptr(); N = 128
-def report(name, nblocks):
-    torch.cuda.synchronize()
-    buf = np.zeros(nblocks * 8, dtype=np.uint64)
-    L = m.lib(); L.mc_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    assert L.mc_debug_read_stamps(buf.ctypes.data, nblocks * 8) == 0
-    raw = buf.reshape(-1, 8)
+L = m.lib()
+def run(name, fn, tu="gemm"):
+    rd = getattr(L, "mc_debug_read_stamps_" + tu); rd.argtypes = [ctypes.c_void_p, ctypes.c_int]; clr = getattr(L, "mc_debug_clear_stamps_" + tu)
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); assert clr() == 0
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); fn(); b.record(); torch.cuda.synchronize()
+    buf = np.zeros(8192 * 8, dtype=np.uint64)
+    assert rd(buf.ctypes.data, 8192 * 8) == 0
+    raw = buf.reshape(-1, 8); raw = raw[raw[:, 3] != 0]
     rt = (raw[:, 2] >> np.uint64(32)).astype(np.float64)          # loop duration in 100 MHz ticks
+    accS = (raw[:, 3] >> np.uint64(32)).astype(np.float64); nk = (raw[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.float64)
     raw[:, 2] = raw[:, 2] & np.uint64(0xFFFFFFFF)
-    b = raw.astype(np.float64)
-    print("   shader clock during the K loop: %.2f GHz (median over workgroups)" % float(np.median(b[:, 0] / rt * 0.1)))
-    nk = b[:, 3].mean()
-    print("%-26s blocks %4d nk %4d | consumer/K-step: total %6.0f  mfma-section %6.0f  barrier-wait %6.0f | producer/K-step: commit(+load wait) %6.0f  fetch-issue %6.0f  lds-drain %5.0f  barrier-wait %6.0f"
-          % (name, nblocks, nk, (b[:, 0] / b[:, 3]).mean(), (b[:, 1] / b[:, 3]).mean(), (b[:, 2] / b[:, 3]).mean(),
-             (b[:, 4] / b[:, 3]).mean(), (b[:, 5] / b[:, 3]).mean(), (b[:, 6] / b[:, 3]).mean(), (b[:, 7] / b[:, 3]).mean()))
-C, H, fs, F, pad = 96, 16, 5, 192, 2; M = 16
-img, W, hid = R(C*H*H, N), R(C*fs*fs, F), R(F*M*M, N)
-out, din = torch.empty(F*M*M, N, device="cuda"), torch.empty(C*H*H, N, device="cuda")
-geo = (N, C, H, H, F, fs, -pad, 1, M, M, 1)
-for _ in range(3): m.call("mc_conv_filter_acts", P(img), P(W), P(out), *geo, 0.0, 1.0, None)
-report("conv2 fwd", 512)
-for _ in range(3): m.call("mc_conv_img_acts", P(hid), P(W), P(din), *geo, 0.0, 1.0, None)
-report("conv2 bwd-data", 256)
-ps = m.lib().mc_conv_weight_acts_pick_partial_sum(N, C, F, fs, M * M, 1)
-tmp = torch.empty((M*M//ps)*C*fs*fs, F, device="cuda")
-for _ in range(3): m.call("mc_conv_weight_acts", P(img), P(hid), P(tmp), *geo, ps, 0.0, 1.0, None)
-report("conv2 wgrad ps=%d" % ps, 512)
-C3, H3, M3 = 192, 8, 8
-img3, W3, hid3 = R(C3*H3*H3, N), R(C3*9, 192), R(192*M3*M3, N)
-out3, din3 = torch.empty(192*M3*M3, N, device="cuda"), torch.empty(C3*H3*H3, N, device="cuda")
-geo3 = (N, C3, H3, H3, 192, 3, -1, 1, M3, M3, 1)
-for _ in range(3): m.call("mc_conv_filter_acts", P(img3), P(W3), P(out3), *geo3, 0.0, 1.0, None)
-report("conv3 fwd", 192)
-for _ in range(3): m.call("mc_conv_img_acts", P(hid3), P(W3), P(din3), *geo3, 0.0, 1.0, None)
-report("conv3 bwd-data", 192)
-Wc, xc, yc = R(160, 192), R(192, 1024 * N), torch.empty(160, 1024 * N, device="cuda")
-for _ in range(3): m.call("mc_gemm", P(Wc), P(xc), P(yc), 160, 1024 * N, 192, 0, 0, 192, 1024 * N, 1024 * N, 0.0, 1.0, None, 0, None, 0, None)
-report("cccp1 fwd 160x131072x192", 1024)
-A, B, Cm = R(2400, 192), R(2400, 32768), torch.empty(192, 32768, device="cuda")
-for _ in range(3): m.call("mc_gemm", P(A), P(B), P(Cm), 192, 32768, 2400, 1, 0, 192, 32768, 32768, 0.0, 1.0, None, 0, None, 0, None)
-report("gemm 192x32768x2400 tn", 512)
+    bb = raw.astype(np.float64)
+    clk = float(np.median(bb[:, 0] / rt * 0.1))
+    print("%-28s %7.1f us  wgs %4d  nk %5.1f  clk %.2f GHz | consumer: loop %7.0f cyc = %5.1f us (per K-step: mfma %5.0f, barrier %4.0f), stores %6.0f cyc | producer/K-step: commit %4.0f fetch %5.0f barrier %5.0f"
+          % (name, a.elapsed_time(b) * 1e3, len(raw), nk.mean(), clk, bb[:, 0].mean(), bb[:, 0].mean() / clk / 1e3, (bb[:, 1] / nk).mean(), (bb[:, 2] / nk).mean(),
+             accS.mean(), (bb[:, 4] / nk).mean(), (bb[:, 5] / nk).mean(), (bb[:, 7] / nk).mean()))
+which = sys.argv[1] if len(sys.argv) > 1 else "gemm"
+def gemm(mm, nn, kk, ta, tb, name):
+    A = R(kk, mm) if ta else R(mm, kk); B = R(nn, kk) if tb else R(kk, nn); C = torch.empty(mm, nn, device="cuda")
+    wsb = L.mc_gemm_workspace_bytes(mm, nn, kk); ws = torch.empty(max(1, wsb // 4), device="cuda")
+    run(name, lambda: m.call("mc_gemm", P(A), P(B), P(C), mm, nn, kk, ta, tb, A.shape[1], B.shape[1], nn, 0.0, 1.0, None, 0, P(ws), wsb, None))
+def conv(name, C, H, fs, F, pad, which="fbw"):
+    M = H + 2 * pad - fs + 1
+    img, W, hid = R(C*H*H, N), R(C*fs*fs, F), R(F*M*M, N)
+    out, din = torch.empty(F*M*M, N, device="cuda"), torch.empty(C*H*H, N, device="cuda")
+    geo = (N, C, H, H, F, fs, -pad, 1, M, M, 1)
+    if "f" in which: run(name + " fwd", lambda: m.call("mc_conv_filter_acts", P(img), P(W), P(out), *geo, 0.0, 1.0, None), "fwd")
+    if "b" in which: run(name + " bwd", lambda: m.call("mc_conv_img_acts", P(hid), P(W), P(din), *geo, 0.0, 1.0, None), "bwd")
+    if "w" in which:
+        wsb = L.mc_conv_weight_grad_workspace_bytes(N, C, F, fs, M * M, 1); ws = torch.empty(max(1, wsb // 4), device="cuda"); dw = torch.empty(C*fs*fs, F, device="cuda")
+        run(name + " wgrad", lambda: m.call("mc_conv_weight_grad", P(img), P(hid), P(dw), *geo, 0.0, 1.0, P(ws), wsb, None), "wgrad")
+if which == "gemm":
+    gemm(160, 131072, 192, 0, 0, "cccp1 fwd"); gemm(192, 131072, 160, 1, 0, "cccp1 bwd"); gemm(160, 192, 131072, 0, 1, "cccp1 wgrad")
+    gemm(96, 131072, 160, 0, 0, "cccp2 fwd"); gemm(160, 131072, 96, 1, 0, "cccp2 bwd"); gemm(96, 160, 131072, 0, 1, "cccp2 wgrad")
+    gemm(192, 32768, 192, 0, 0, "cccp3 fwd"); gemm(192, 32768, 192, 1, 0, "cccp3 bwd"); gemm(192, 192, 32768, 0, 1, "cccp3 wgrad")
+    gemm(192, 8192, 192, 0, 0, "cccp5 fwd"); gemm(192, 8192, 192, 1, 0, "cccp5 bwd"); gemm(192, 192, 8192, 0, 1, "cccp5 wgrad")
+else:
+    conv("conv1", 3, 32, 5, 192, 2, "fw"); conv("conv2", 96, 16, 5, 192, 2); conv("conv3", 192, 8, 3, 192, 1)
