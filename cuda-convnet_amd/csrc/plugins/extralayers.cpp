@@ -34,11 +34,21 @@ protected:
         return inputFeatures / (_channels * _in);
     }
 
-    void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE) override {
+    bool readsReluBits() const override { return _channels == 1; }
+
+    void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override {
         const int N = numCases(), P = pixels(_inputs[inpIdx]->rows()), cols = P * N;
         NeuronLayer* relu = fusableRelu();
         if (relu) relu->setFusedIntoProducer(true);
         const size_t wsb = mc_gemm_workspace_bytes(_out, cols, _in);
+        // the relu's gradient mask as bits for the dense product above (FCLayer::fpropActs)
+        const bool bits = relu && passType == PASS_TRAIN && scaleTargets == 0 && wsb == 0 && _channels == 1 && relu->wantsBits();
+        if (relu) relu->setBitsValid(bits);
+        if (bits) {
+            RT_MC(mc_gemm_relu_bits(_weights[inpIdx].getW(), _inputs[inpIdx]->data(), getActs().data(), _out, cols, _in, 0, 0, _in, cols, cols,
+                                    _biases->getW(), relu->bitsBuffer(_out, cols), ST()));
+            return;
+        }
         for (int ch = 0; ch < _channels; ch++) {
             const float* W = _weights[inpIdx].getW() + (size_t)ch * _out * _in;
             const float* X = _inputs[inpIdx]->data() + (size_t)ch * _in * cols;
@@ -51,6 +61,12 @@ protected:
     void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE) override {
         const int N = numCases(), P = pixels(_prev[inpIdx]->getNumOutputs()), cols = P * N;
         const size_t wsb = mc_gemm_workspace_bytes(_in, cols, _out);
+        const unsigned* bits = (scaleTargets == 0.f && _channels == 1) ? claimReluGradBits(inpIdx) : nullptr;
+        if (bits) {   // the input relu's mask arrives as bits
+            RT_MC(mc_gemm_relu_grad_bits(_weights[inpIdx].getW(), v.data(), _prev[inpIdx]->getActsGrad().data(), _in, cols, _out, 1, 0, _in, cols, cols,
+                                         1.f, bits, ST()));
+            return;
+        }
         const float* mask = scaleTargets == 0.f ? claimReluGradMask(inpIdx) : nullptr;   // see FCLayer::bpropActs
         for (int ch = 0; ch < _channels; ch++) {
             const float* W = _weights[inpIdx].getW() + (size_t)ch * _out * _in;

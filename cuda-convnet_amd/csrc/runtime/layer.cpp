@@ -220,6 +220,23 @@ const float* Layer::claimReluGradMask(int inpIdx) {
     return nl->getActs().data();
 }
 
+bool NeuronLayer::wantsBits() {
+    static const bool off = getenv("MC_NO_RELU_BITS") != nullptr;
+    return !off && _next.size() == 1 && _next[0]->readsReluBits() && canFuseGradMask();
+}
+
+unsigned* NeuronLayer::bitsBuffer(int rows, int ld) {
+    _bits.resize((rows + 31) / 32, ld);
+    return reinterpret_cast<unsigned*>(_bits.data());
+}
+
+const unsigned* Layer::claimReluGradBits(int inpIdx) {
+    NeuronLayer* nl = dynamic_cast<NeuronLayer*>(_prev[inpIdx]);
+    if (!nl || !nl->canFuseGradMask() || !nl->validBits()) return nullptr;
+    nl->setGradMasked();
+    return nl->validBits();
+}
+
 void NeuronLayer::bpropActs(DevMat& v, int, float scaleTargets, PASS_TYPE passType) {
     if (_gradMasked) {   // the layer above stored grad * (act > 0) straight into the shared gradient matrix
         _gradMasked = false;
@@ -433,13 +450,20 @@ FCLayer::FCLayer(ConvNet* convNet, PyObject* paramsDict) : WeightLayer(convNet, 
     _bStep = 0.01f;
 }
 
-void FCLayer::fpropActs(int inpIdx, float scaleTargets, PASS_TYPE) {
+void FCLayer::fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) {
     const int N = numCases(), in = _inputs[inpIdx]->rows(), out = _numOutputs;
     NeuronLayer* relu = fusableRelu();
     if (relu) relu->setFusedIntoProducer(true);
     const size_t wsb = mc_gemm_workspace_bytes(out, N, in);
-    RT_MC(mc_gemm(_weights[inpIdx].getW(), _inputs[inpIdx]->data(), getActs().data(), out, N, in, 0, 0, in, N, N, scaleTargets, 1.f,
-                  scaleTargets == 0 ? _biases->getW() : nullptr, relu ? MC_NEURON_RELU : MC_NEURON_NONE, wsb ? workspace(wsb) : nullptr, wsb, ST()));
+    // a relu whose gradient mask the layer above can read as bits: write them from this product's epilogue (unsplit products only)
+    const bool bits = relu && passType == PASS_TRAIN && scaleTargets == 0 && wsb == 0 && relu->wantsBits();
+    if (relu) relu->setBitsValid(bits);
+    if (bits)
+        RT_MC(mc_gemm_relu_bits(_weights[inpIdx].getW(), _inputs[inpIdx]->data(), getActs().data(), out, N, in, 0, 0, in, N, N, _biases->getW(),
+                                relu->bitsBuffer(out, N), ST()));
+    else
+        RT_MC(mc_gemm(_weights[inpIdx].getW(), _inputs[inpIdx]->data(), getActs().data(), out, N, in, 0, 0, in, N, N, scaleTargets, 1.f,
+                      scaleTargets == 0 ? _biases->getW() : nullptr, relu ? MC_NEURON_RELU : MC_NEURON_NONE, wsb ? workspace(wsb) : nullptr, wsb, ST()));
 }
 
 void FCLayer::bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE) {
@@ -447,8 +471,11 @@ void FCLayer::bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE) {
     const size_t wsb = mc_gemm_workspace_bytes(in, N, out);
     // the relu gradient mask of the layer below goes into this product's store (one pass over the gradient instead of
     // three); measured +0.9 % on the NIN step once the epilogue's mask reads became branch-free buffer loads
-    const float* mask = scaleTargets == 0.f ? claimReluGradMask(inpIdx) : nullptr;
-    if (mask)
+    const unsigned* bits = scaleTargets == 0.f ? claimReluGradBits(inpIdx) : nullptr;
+    const float* mask = (scaleTargets == 0.f && !bits) ? claimReluGradMask(inpIdx) : nullptr;
+    if (bits)
+        RT_MC(mc_gemm_relu_grad_bits(_weights[inpIdx].getW(), v.data(), _prev[inpIdx]->getActsGrad().data(), in, N, out, 1, 0, in, N, N, 1.f, bits, ST()));
+    else if (mask)
         RT_MC(mc_gemm_relu_grad(_weights[inpIdx].getW(), v.data(), _prev[inpIdx]->getActsGrad().data(), in, N, out, 1, 0, in, N, N, 0.f, 1.f, mask, N,
                                 wsb ? workspace(wsb) : nullptr, wsb, ST()));
     else
@@ -561,13 +588,21 @@ ConvLayer::ConvLayer(ConvNet* convNet, PyObject* paramsDict) : LocalLayer(convNe
     _sharedBiases = pyDictGetInt(paramsDict, "sharedBiases") != 0;
 }
 
-void ConvLayer::fpropActs(int i, float scaleTargets, PASS_TYPE) {
+void ConvLayer::fpropActs(int i, float scaleTargets, PASS_TYPE passType) {
     // bias (+ an in-place relu consumer) ride in the contraction's epilogue when the biases are
     // shared per filter: the same values as convFilterActs + reshape/addVector (layer.cu:476-487)
     const bool first = scaleTargets == 0;
     NeuronLayer* relu = _sharedBiases ? fusableRelu() : nullptr;
     if (relu) relu->setFusedIntoProducer(true);
     const float* in = sparse(i) ? sparseInput(i, *_inputs[i]) : _inputs[i]->data();
+    // (see FCLayer::fpropActs) the relu's gradient mask as bits, written by this product's epilogue
+    const bool bits = relu && passType == PASS_TRAIN && first && !sparse(i) && _groups->at(i) == 1 && relu->wantsBits();
+    if (relu) relu->setBitsValid(bits);
+    if (bits)
+        RT_MC(mc_conv_filter_acts_relu_bits(in, _weights[i].getW(), getActs().data(), _biases->getW(), relu->bitsBuffer(_numFilters, _modules * numCases()),
+                                            numCases(), _channels->at(i), _imgSize->at(i), _imgSize->at(i), _numFilters, _filterSize->at(i),
+                                            _padding->at(i), _stride->at(i), _modulesX, _modulesX, ST()));
+    else
     RT_MC(mc_conv_filter_acts_fused(in, _weights[i].getW(), getActs().data(), (first && _sharedBiases) ? _biases->getW() : nullptr,
                                     relu ? MC_NEURON_RELU : MC_NEURON_NONE, CONV_GEOM(i), scaleTargets, 1.f, ST()));
     if (first && !_sharedBiases) RT_MC(mc_add_row_vector(getActs().data(), _biases->getW(), _numFilters * _modules, numCases(), 1.f, ST()));

@@ -142,6 +142,8 @@ public:
     virtual void postInit();
     bool isGradConsumer();
     virtual bool isGradProducer() { return true; }
+    // true for layers whose backward-data product can read the relu gradient mask of its input as bits (dense products)
+    virtual bool readsReluBits() const { return false; }
 
     // weight layers override these
     virtual void updateWeights() {}
@@ -161,6 +163,9 @@ protected:
     // passes it on in place, returns that relu's output (the mask for mc_*_relu_grad) and tells the neuron
     // layer to skip its own pass over the gradient; otherwise nullptr.
     const float* claimReluGradMask(int inpIdx);
+    // The same claim when the relu's producer wrote the mask as bits this pass (mc_kernels.h "relu bit masks"); nullptr otherwise
+    // (nothing is claimed then: ask claimReluGradMask next).
+    const unsigned* claimReluGradBits(int inpIdx);
 
     ConvNet* _convNet;
     std::vector<Layer*> _prev, _next;
@@ -185,6 +190,12 @@ public:
     // true when the consumer of this layer's output can apply the relu gradient mask itself
     bool canFuseGradMask();
     void setGradMasked() { _gradMasked = true; }
+    // Relu masks as bits: the producing layer asks wantsBits() (the one consumer is a dense product that can read them and
+    // this relu passes its gradient on in place), writes them into bitsBuffer() from its epilogue and says so every pass.
+    bool wantsBits();
+    unsigned* bitsBuffer(int rows, int ld);
+    void setBitsValid(bool v) { _bitsValid = v; }
+    const unsigned* validBits() const { return _bitsValid ? reinterpret_cast<const unsigned*>(_bits.data()) : nullptr; }
 
 protected:
     void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
@@ -192,6 +203,8 @@ protected:
     Neuron* _neuron;
     bool _fused = false;
     bool _gradMasked = false;   // this pass's gradient already carries the relu mask (see claimReluGradMask)
+    bool _bitsValid = false;
+    DevMat _bits;               // 32-bit words held in a float matrix: ((rows + 31) / 32, ld)
 };
 
 class WeightLayer : public Layer {
@@ -225,6 +238,7 @@ protected:
 class FCLayer : public WeightLayer {
 public:
     FCLayer(ConvNet* convNet, PyObject* paramsDict);
+    bool readsReluBits() const override { return true; }
 
 protected:
     void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
