@@ -164,6 +164,47 @@ __global__ void k_splitk_reduce_bits(const float* __restrict__ slabs, float* C, 
     }
 }
 
+// float4 form (n % 4 == 0, 16-byte aligned): a workgroup takes 32 rows x 128 columns; thread (prow, c4) sums rows prow, prow + 8, ...
+// (bit order) of column group c4 -- 512 contiguous bytes per row and wave -- and the eight threads of a column group OR their
+// partial words together in LDS.
+__global__ void __launch_bounds__(256) k_splitk_reduce_bits4(const float4* __restrict__ slabs, float* C, unsigned* bits, int m, int n, int chunks,
+                                                             float alpha, const float* __restrict__ bias, int act) {
+    __shared__ unsigned sh[128];
+    const int c4 = threadIdx.x & 31, prow = threadIdx.x >> 5;
+    const int colTiles = (n + 127) >> 7, blocks32 = (m + 31) >> 5, n4 = n >> 2;
+    const size_t total4 = (size_t)m * n4;
+    for (int tile = blockIdx.x; tile < blocks32 * colTiles; tile += gridDim.x) {
+        const int rb = tile / colTiles, ct = tile - rb * colTiles, j = ct * 128 + c4 * 4;
+        if (threadIdx.x < 128) sh[threadIdx.x] = 0;
+        __syncthreads();
+        unsigned w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+        if (j < n) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int p = prow + 8 * k, i = rb * 32 + bit_row(p);
+                if (i < m) {
+                    const size_t e = (size_t)i * n4 + (j >> 2);
+                    float4 acc = slabs[e];
+                    for (int q = 1; q < chunks; ++q) {
+                        const float4 x = slabs[(size_t)q * total4 + e];
+                        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+                    }
+                    float4 v = make_float4(alpha * acc.x, alpha * acc.y, alpha * acc.z, alpha * acc.w);
+                    if (bias) { const float b = bias[i]; v.x += b; v.y += b; v.z += b; v.w += b; }
+                    if (act == MC_NEURON_RELU) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }
+                    reinterpret_cast<float4*>(C)[e] = v;
+                    w0 |= (v.x > 0.f) ? (1u << p) : 0u; w1 |= (v.y > 0.f) ? (1u << p) : 0u;
+                    w2 |= (v.z > 0.f) ? (1u << p) : 0u; w3 |= (v.w > 0.f) ? (1u << p) : 0u;
+                }
+            }
+            atomicOr(&sh[c4 * 4 + 0], w0); atomicOr(&sh[c4 * 4 + 1], w1); atomicOr(&sh[c4 * 4 + 2], w2); atomicOr(&sh[c4 * 4 + 3], w3);
+        }
+        __syncthreads();
+        if (threadIdx.x < 128 && ct * 128 + (int)threadIdx.x < n) bits[(size_t)rb * n + ct * 128 + threadIdx.x] = sh[threadIdx.x];
+        __syncthreads();
+    }
+}
+
 __global__ void k_relu_bits_from_acts(const float* __restrict__ acts, unsigned* bits, int m, int n, int ld) {
     const int blocks32 = (m + 31) >> 5;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < (size_t)blocks32 * n; t += (size_t)gridDim.x * blockDim.x) {
@@ -310,6 +351,11 @@ static int conv_fwd_entry(const float* images, const float* filters, float* targ
                                            0.f, 1.f, slabs, kc, nullptr, S(s));
             if (rc) return rc;
             if (reluBits) {
+                if (cols % 4 == 0 && aligned16(targets) && aligned16(slabs)) {
+                    const long tiles = (long)ceil_div(numFilters, 32) * ceil_div(cols, 128);
+                    hipLaunchKernelGGL(k_splitk_reduce_bits4, dim3((unsigned)(tiles < 16L * num_cus() ? tiles : 16L * num_cus())), dim3(256), 0, S(s),
+                                       reinterpret_cast<const float4*>(slabs), targets, reluBits, numFilters, (int)cols, chunks, scaleOutput, biases, neuron);
+                } else
                 hipLaunchKernelGGL(k_splitk_reduce_bits, dim3(grid_items((size_t)ceil_div(numFilters, 32) * cols)), dim3(TPB), 0, S(s), slabs, targets,
                                    reluBits, numFilters, (int)cols, chunks, scaleOutput, biases, neuron);
                 return launch_status("conv split-K reduce (bits)");
@@ -406,6 +452,9 @@ size_t mc_gemm_workspace_bytes(int m, int n, int k) {
     const int chunks = pick_gemm_chunks(m, n, k);
     return chunks > 1 ? (size_t)chunks * m * n * sizeof(float) : 0;
 }
+// (Measured and dropped: cutting the 160 / 192 columns of the dense weight gradients into 128 + remainder, two products on
+// exact tiles instead of one padded to 256 columns -- cccp1 121 -> 115 us, but cccp2 67 -> 75 and cccp3 42 -> 48: the second
+// launch and reduction cost more than the padding, and these products are bound by their k-contiguous loaders anyway.)
 
 static int gemm_entry(const char* who, const float* A, const float* B, float* C, int m, int n, int k, int transA, int transB, int lda,
                       int ldb, int ldc, float scaleTargets, float scaleOutput, const float* rowBias, int neuron, const float* mask,
