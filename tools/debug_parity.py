@@ -10,7 +10,8 @@ from run_net_step import make_masks
 
 net_name, cases = sys.argv[1], int(sys.argv[2])
 mini = int(sys.argv[3]) if len(sys.argv) > 3 else cases
-layers, dims, classes = modelutil.load_net(net_name)
+IW = float(os.environ.get("INIT_W", "0"))
+layers, dims, classes = modelutil.load_net(net_name, init_w=IW)
 names = [l["name"] for l in layers if not l["type"].startswith("cost.")]
 out = os.path.join(tempfile.mkdtemp(), "r.npz")
 code = r'''
@@ -18,7 +19,7 @@ import sys, numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, %r)
 import modelutil, libkernel
 from run_net_step import make_masks
-layers, dims, classes = modelutil.load_net(%r)
+layers, dims, classes = modelutil.load_net(%r, init_w=%r)
 data = modelutil.synthetic_batch(dims, classes, %d)
 libkernel.initModel(layers, %d, 0)
 libkernel.setDropoutMasks([m for mb in make_masks(layers, %d, %d) for m in mb])
@@ -33,7 +34,7 @@ for l in layers:
     if "weights" in l:
         res["W:" + l["name"]] = np.array(l["weightsInc"][0]); res["B:" + l["name"]] = np.array(l["biasesInc"])
 np.savez(%r, **res)
-''' % (os.path.join(ROOT, "cuda-convnet_amd"), os.path.join(ROOT, "tests"), net_name, cases, mini, cases, mini, names, out)
+''' % (os.path.join(ROOT, "cuda-convnet_amd"), os.path.join(ROOT, "tests"), net_name, IW, cases, mini, cases, mini, names, out)
 r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
 print(r.stdout[-500:], r.stderr[-2000:])
 got = dict(np.load(out))
