@@ -213,6 +213,69 @@ __global__ void __launch_bounds__(256) k_max_undo_2d(const float* __restrict__ i
         }
 }
 
+// Stride-2 pooling (every shipped max pool: 3x3 / 2 and 2x2 / 2): a thread owns a 2x2 block of input pixels and walks block
+// rows.  The block's pixels share their windows (at most 2 x 2 of them for 3x3 / 2), so each window's (maxActs, maxGrads) pair
+// is loaded once per block instead of once per pixel: 4 image loads + <= 8 window loads + 4 stores per 4 pixels, against
+// 4 x (1 + <= 8 + 1).  Per pixel the windows are visited in the same (my, mx) order as k_max_undo: same sum, same bits.
+template <bool RELU>
+__global__ void __launch_bounds__(256) k_max_undo_s2(const float* __restrict__ imgs, const float* __restrict__ maxGrads,
+                                                     const float* __restrict__ maxActs, float* target, int N, int imgSize, int subsX,
+                                                     int startX, int outputsX, float sT, float sO, Map2D mp) {
+    typedef Vec<4> VV;
+    const int LX = 1 << mp.lxShift;
+    const int nl = threadIdx.x & (LX - 1), xl = threadIdx.x >> mp.lxShift;
+    const int xb = blockIdx.x % mp.xBlocks, yb = blockIdx.x / mp.xBlocks;
+    const int bx = xb * (256 >> mp.lxShift) + xl, x0 = 2 * bx;
+    const int c = blockIdx.y;
+    if (x0 >= imgSize) return;
+    const int numOut = outputsX * outputsX, blocksY = (imgSize + 1) >> 1;
+    const int lim = startX + 2 * (outputsX - 1) + subsX;
+    const bool x1in = x0 + 1 < imgSize;
+    // windows that can hold pixel column x0 or x0 + 1 (empty when the block lies outside [startX, lim))
+    int xlo = 0, xhi = 0;
+    {
+        const int a = max(x0, startX), b = min(x0 + 1, lim - 1);
+        if (a <= b) { int t0, t1; out_range(a, startX, subsX, 2, outputsX, xlo, t1); out_range(b, startX, subsX, 2, outputsX, t0, xhi); }
+    }
+    const int byEnd = min(blocksY, (yb + 1) * mp.band);
+    const size_t ibase = (size_t)c * imgSize * imgSize * N, obase = (size_t)c * numOut * N;
+    for (int n = nl * 4; n < N; n += LX * 4)
+        for (int by = yb * mp.band; by < byEnd; ++by) {
+            const int y0 = 2 * by;
+            const bool y1in = y0 + 1 < imgSize;
+            const size_t e00 = ibase + (size_t)(y0 * imgSize + x0) * N + n, rowStep = (size_t)imgSize * N;
+            const float4 z = VV::splat(0.f);
+            const float4 i00 = VV::ld(imgs + e00), i01 = x1in ? VV::ld(imgs + e00 + N) : z;
+            const float4 i10 = y1in ? VV::ld(imgs + e00 + rowStep) : z, i11 = (y1in && x1in) ? VV::ld(imgs + e00 + rowStep + N) : z;
+            float4 p00 = z, p01 = z, p10 = z, p11 = z;
+            int ylo = 0, yhi = 0;
+            {
+                const int a = max(y0, startX), b = min(y0 + 1, lim - 1);
+                if (a <= b) { int t0, t1; out_range(a, startX, subsX, 2, outputsX, ylo, t1); out_range(b, startX, subsX, 2, outputsX, t0, yhi); }
+            }
+            for (int my = ylo; my < yhi; ++my) {
+                const int wy = startX + 2 * my;
+                const bool r0 = y0 >= wy && y0 < wy + subsX, r1 = y0 + 1 >= wy && y0 + 1 < wy + subsX;
+                for (int mx = xlo; mx < xhi; ++mx) {
+                    const int wx = startX + 2 * mx;
+                    const bool c0 = x0 >= wx && x0 < wx + subsX, c1 = x0 + 1 >= wx && x0 + 1 < wx + subsX;
+                    const size_t o = obase + (size_t)(my * outputsX + mx) * N + n;
+                    const float4 a = VV::ld(maxActs + o), g = VV::ld(maxGrads + o);
+                    if (r0 && c0) p00 = vadd(p00, veqmul(i00, a, g));
+                    if (r0 && c1) p01 = vadd(p01, veqmul(i01, a, g));
+                    if (r1 && c0) p10 = vadd(p10, veqmul(i10, a, g));
+                    if (r1 && c1) p11 = vadd(p11, veqmul(i11, a, g));
+                }
+            }
+            if (RELU) { p00 = vposmask(i00, p00); p01 = vposmask(i01, p01); p10 = vposmask(i10, p10); p11 = vposmask(i11, p11); }
+            auto put = [&](size_t e, float4 p) { VV::st(target + e, sT == 0.f ? vscale(p, sO) : blend(VV::ld(target + e), p, sT, sO)); };
+            put(e00, p00);
+            if (x1in) put(e00 + N, p01);
+            if (y1in) put(e00 + rowStep, p10);
+            if (y1in && x1in) put(e00 + rowStep + N, p11);
+        }
+}
+
 // rows: items along the walked axis, cols: items along x; channels on grid.y (<= 65535)
 inline Map2D make_map2d(int N, int rows, int cols, int C, dim3& grid) {
     Map2D mp;
@@ -400,7 +463,7 @@ __global__ void k_cmrnorm(const float* __restrict__ imgs, float* denoms, float* 
 // every step, so each input is read once (plus SF-1 halo maps per segment) instead of SF times, and the sum has the
 // order -- and the bits -- of k_cmrnorm (maps outside [0, C) enter as +0).
 template <int V, int SF>
-__global__ void k_cmrnorm_walk(const float* __restrict__ imgs, float* denoms, float* target, int N, int C, int imgPix, int segLen,
+__global__ void k_cmrnorm_walk(const float* __restrict__ imgs, float* __restrict__ denoms, float* __restrict__ target, int N, int C, int imgPix, int segLen,
                                float addScale, float powScale, float k) {
     typedef Vec<V> VV;
     typedef typename VV::T T;
@@ -419,11 +482,13 @@ __global__ void k_cmrnorm_walk(const float* __restrict__ imgs, float* denoms, fl
             const int f = c0 - SF / 2 + j;
             x[j + 1] = (f >= 0 && f < C) ? VV::ld(imgs + f * mapStride + col) : VV::splat(0.f);
         }
+        auto fetch = [&](int f) { return f < C ? VV::ld(imgs + f * mapStride + col) : VV::splat(0.f); };
+        T nxt = fetch(c0 - SF / 2 + SF - 1);
         for (int c = c0; c < c1; ++c) {
 #pragma unroll
             for (int j = 0; j < SF - 1; ++j) x[j] = x[j + 1];
-            const int f = c - SF / 2 + SF - 1;
-            x[SF - 1] = f < C ? VV::ld(imgs + f * mapStride + col) : VV::splat(0.f);
+            x[SF - 1] = nxt;
+            nxt = fetch(c + 1 - SF / 2 + SF - 1);   // requested a whole step ahead of its use
             T sum = VV::splat(0.f);
 #pragma unroll
             for (int j = 0; j < SF; ++j) sum = vadd(sum, vmul(x[j], x[j]));
@@ -455,6 +520,78 @@ __global__ void k_cmrnorm_undo(const float* __restrict__ outGrads, const float* 
         const size_t i = (size_t)row * N + n;
         const typename VV::T v = vadd(vmul(VV::ld(inputs + i), s), vmul(VV::ld(outGrads + i), vpow(VV::ld(denoms + i), -powScale)));
         VV::st(target + i, sT == 0.f ? vscale(v, sO) : blend(VV::ld(target + i), v, sT, sO));
+    }
+}
+
+// The undo for the centred window of SF maps in ONE pass, walking the map axis like k_cmrnorm_walk.  The reference runs two
+// kernels: kRNormUndoPrelims overwrites acts with t = (-2 addScale pow) outGrads * acts / denoms, then kFRNormUndo sums t over
+// the mirrored window (conv_util.cu:1603-1615, 1115-1181).  Here a lane owns a (pixel, image) column and a segment of maps,
+// forms t of the map entering the window on the fly and keeps the window's SF terms in registers.  acts is not READ at all:
+// the forward pass stored acts = inputs * denoms^-pow with this file's vpow, so the same expression gives the same bits (and
+// denoms^-pow is needed for the second term anyway); that is what lets neighbouring segments recompute their halo terms
+// while the owner overwrites acts (the reference's side effect, kept).  Same terms, same order of the window sum as the
+// two-pass form (maps outside [0, C) enter as +0): bit-identical target and acts.  Traffic: 3 reads + 2 writes per element
+// (+ (SF-1)/segLen halo) against 5 reads + 2 writes of the two passes.
+template <int V, int SF>
+__global__ void k_cmrnorm_undo_walk(const float* __restrict__ outGrads, const float* __restrict__ denoms, const float* __restrict__ inputs,
+                                    float* __restrict__ acts, float* __restrict__ target, int N, int C, int imgPix, int segLen, float scale,
+                                    float powScale, float sT, float sO) {
+    typedef Vec<V> VV;
+    typedef typename VV::T T;
+    constexpr int LEAD = SF / 2;           // the window of map c is [c - (SF - 1 - LEAD), c + LEAD]
+    constexpr int BACK = SF - 1 - LEAD;
+    const int nChunks = N / V;
+    const int nSeg = (C + segLen - 1) / segLen;
+    const size_t total = (size_t)nSeg * imgPix * nChunks;
+    for (size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(item % nChunks) * V;
+        const size_t rest = item / nChunks;
+        const int px = (int)(rest % imgPix), seg = (int)(rest / imgPix);
+        const int c0 = seg * segLen, c1 = min(C, c0 + segLen);
+        const size_t col = (size_t)px * N + n, mapStride = (size_t)imgPix * N;
+        T t[SF];            // t[j]: term of map c - BACK + j
+        T xs[LEAD + 1];     // inputs of maps c .. c + LEAD
+        T gp[LEAD + 1];     // outGrads * denoms^-pow of the same maps
+        struct Raw { T g, d, x; };
+        auto fetch = [&](int f) {   // a map outside [0, C) contributes a zero term (g = x = 0, d = 1)
+            Raw r;
+            if (f < 0 || f >= C) { r.g = VV::splat(0.f); r.d = VV::splat(1.f); r.x = VV::splat(0.f); return r; }
+            const size_t i = f * mapStride + col;
+            r.g = VV::ld(outGrads + i); r.d = VV::ld(denoms + i); r.x = VV::ld(inputs + i);
+            return r;
+        };
+        // term of map f (and, for the centre queue, its input and grad * denom^-pow); own = this segment stores acts[f]
+        auto take = [&](const Raw& r, int f, T& tf, T& xf, T& gpf, bool own) {
+            const T p = vpow(r.d, -powScale);
+            xf = r.x;
+            tf = vdiv(vmul(vscale(r.g, scale), vmul(r.x, p)), r.d);
+            gpf = vmul(r.g, p);
+            if (own && f >= 0 && f < C) VV::st(acts + f * mapStride + col, tf);
+        };
+#pragma unroll
+        for (int j = 0; j < SF - 1; ++j) {   // window of map c0 without its last member: maps c0 - BACK .. c0 + LEAD - 1
+            const int f = c0 - BACK + j;
+            T xf, gpf;
+            take(fetch(f), f, t[j + 1], xf, gpf, f >= c0 && f < c1);
+            if (j >= BACK) { xs[j - BACK + 1] = xf; gp[j - BACK + 1] = gpf; }
+        }
+        Raw nxt = fetch(c0 + LEAD);
+        for (int c = c0; c < c1; ++c) {
+            const Raw cur = nxt;
+            nxt = fetch(c + 1 + LEAD);   // requested a whole step ahead of its use
+#pragma unroll
+            for (int j = 0; j < SF - 1; ++j) t[j] = t[j + 1];
+#pragma unroll
+            for (int j = 0; j < LEAD; ++j) { xs[j] = xs[j + 1]; gp[j] = gp[j + 1]; }
+            const int f = c + LEAD;
+            take(cur, f, t[SF - 1], xs[LEAD], gp[LEAD], f < c1);
+            T sum = VV::splat(0.f);
+#pragma unroll
+            for (int j = 0; j < SF; ++j) sum = vadd(sum, t[j]);
+            const T v = vadd(vmul(xs[0], sum), gp[0]);
+            const size_t i = c * mapStride + col;
+            VV::st(target + i, sT == 0.f ? vscale(v, sO) : blend(VV::ld(target + i), v, sT, sO));
+        }
     }
 }
 
@@ -520,6 +657,14 @@ static int max_undo_entry(const char* who, bool relu, const float* images, const
     MC_REQUIRE(numImages > 0 && numFilters > 0 && imgSize > 0 && subsX > 0 && strideX > 0 && outputsX > 0, "%s: non-positive dimension", who);
     MC_REQUIRE((size_t)numFilters * imgSize * imgSize * numImages < (1ull << 31), "%s: tensor exceeds 32-bit indexing", who);
     const bool v = use_vec(numImages, {images, maxGrads, maxActs, target});
+    static const bool nos2 = getenv("MC_MAXUNDO_NOS2") != nullptr;
+    if (v && numFilters <= 65535 && strideX == 2 && subsX <= 4 && !nos2) {
+        dim3 g2;
+        const Map2D mp = make_map2d(numImages, (imgSize + 1) / 2, (imgSize + 1) / 2, numFilters, g2);
+        if (relu) hipLaunchKernelGGL(k_max_undo_s2<true>, g2, dim3(256), 0, S(s), images, maxGrads, maxActs, target, numImages, imgSize, subsX, startX, outputsX, scaleTargets, scaleOutput, mp);
+        else hipLaunchKernelGGL(k_max_undo_s2<false>, g2, dim3(256), 0, S(s), images, maxGrads, maxActs, target, numImages, imgSize, subsX, startX, outputsX, scaleTargets, scaleOutput, mp);
+        return launch_status(who);
+    }
     if (v && numFilters <= 65535) {
         dim3 g2;
         const Map2D mp = make_map2d(numImages, imgSize, imgSize, numFilters, g2);
@@ -650,6 +795,14 @@ int mc_conv_response_norm_cross_map_undo(const float* outGrads, const float* den
     MC_REQUIRE(numImages > 0 && numFilters > 0 && imgSize > 0 && sizeF > 0 && sizeF <= numFilters, "mc_conv_response_norm_cross_map_undo: bad dimension");
     const bool v = use_vec(numImages, {outGrads, denoms, inputs, acts, target});
     const size_t n = (size_t)numFilters * imgSize * imgSize * numImages;
+    static const bool nowalk = getenv("MC_CMRNORM_NOWALK") != nullptr;
+    if (!blocked && sizeF == 5 && numFilters >= 16 && !nowalk) {   // the centred 5-map window of the shipped configs: one pass
+        const int segLen = 16, nSeg = ceil_div(numFilters, segLen);
+        dim3 gw(grid_items((size_t)nSeg * imgSize * imgSize * (numImages / (v ? 4 : 1)))), bw(TPB);
+        if (v) hipLaunchKernelGGL((k_cmrnorm_undo_walk<4, 5>), gw, bw, 0, S(s), outGrads, denoms, inputs, acts, target, numImages, numFilters, imgSize * imgSize, segLen, -2 * addScale * powScale, powScale, scaleTargets, scaleOutput);
+        else hipLaunchKernelGGL((k_cmrnorm_undo_walk<1, 5>), gw, bw, 0, S(s), outGrads, denoms, inputs, acts, target, numImages, numFilters, imgSize * imgSize, segLen, -2 * addScale * powScale, powScale, scaleTargets, scaleOutput);
+        return launch_status("mc_conv_response_norm_cross_map_undo");
+    }
     int rc = undo_prelims(acts, denoms, outGrads, n, -2 * addScale * powScale, v, S(s));
     if (rc) return rc;
     dim3 g(grid_items(n / (v ? 4 : 1))), b(TPB);
