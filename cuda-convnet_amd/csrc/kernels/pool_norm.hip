@@ -176,6 +176,53 @@ __global__ void __launch_bounds__(256) k_pool_2d(const float* __restrict__ imgs,
         }
 }
 
+// k_pool_2d for a compile-time window (2x2, 3x3: every shipped strided pool): the window loop is unrolled and branch-free, so
+// all SIZE^2 loads are in flight together.  A tap outside the image re-reads the nearest tap inside (max: a duplicate changes
+// nothing) or enters the sum as +0 (avg: same order of the in-image terms as the loops of k_pool_2d).
+template <bool MAX, int SIZE>
+__global__ void __launch_bounds__(256) k_pool_fix(const float* __restrict__ imgs, float* __restrict__ target, int N, int imgSize,
+                                                  int startX, int strideX, int outputsX, Map2D mp) {
+    typedef Vec<4> VV;
+    const int LX = 1 << mp.lxShift;
+    const int nl = threadIdx.x & (LX - 1), oxl = threadIdx.x >> mp.lxShift;
+    const int xb = blockIdx.x % mp.xBlocks, yb = blockIdx.x / mp.xBlocks;
+    const int ox = xb * (256 >> mp.lxShift) + oxl;
+    const int c = blockIdx.y;
+    if (ox >= outputsX) return;
+    const int sx = startX + ox * strideX;
+    const int x0 = max(0, sx), x1 = min(imgSize, sx + SIZE);
+    const int numOut = outputsX * outputsX;
+    const int oyEnd = min(outputsX, (yb + 1) * mp.band);
+    const float* src = imgs + (size_t)c * imgSize * imgSize * N;
+    float* dst = target + (size_t)c * numOut * N;
+    for (int n = nl * 4; n < N; n += LX * 4)
+        for (int oy = yb * mp.band; oy < oyEnd; ++oy) {
+            const int sy = startX + oy * strideX;
+            const int y0 = max(0, sy), y1 = min(imgSize, sy + SIZE);
+            float4 v[SIZE][SIZE];
+#pragma unroll
+            for (int dy = 0; dy < SIZE; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < SIZE; ++dx) {
+                    const int y = min(max(sy + dy, y0), y1 - 1), x = min(max(sx + dx, x0), x1 - 1);
+                    v[dy][dx] = VV::ld(src + (size_t)(y * imgSize + x) * N + n);
+                }
+            float4 acc = VV::splat(MAX ? -2e38f : 0.f);
+#pragma unroll
+            for (int dy = 0; dy < SIZE; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < SIZE; ++dx) {
+                    if (MAX) acc = vmax(acc, v[dy][dx]);
+                    else {
+                        const bool in = sy + dy >= y0 && sy + dy < y1 && sx + dx >= x0 && sx + dx < x1;
+                        acc = vadd(acc, in ? v[dy][dx] : VV::splat(0.f));
+                    }
+                }
+            if (!MAX) acc = vdivs(acc, (float)((y1 - y0) * (x1 - x0)));
+            VV::st(dst + (size_t)(oy * outputsX + ox) * N + n, acc);
+        }
+}
+
 template <bool RELU>
 __global__ void __launch_bounds__(256) k_max_undo_2d(const float* __restrict__ imgs, const float* __restrict__ maxGrads,
                                                      const float* __restrict__ maxActs, float* target, int N, int imgSize, int subsX,
@@ -253,18 +300,32 @@ __global__ void __launch_bounds__(256) k_max_undo_s2(const float* __restrict__ i
                 const int a = max(y0, startX), b = min(y0 + 1, lim - 1);
                 if (a <= b) { int t0, t1; out_range(a, startX, subsX, 2, outputsX, ylo, t1); out_range(b, startX, subsX, 2, outputsX, t0, yhi); }
             }
-            for (int my = ylo; my < yhi; ++my) {
-                const int wy = startX + 2 * my;
-                const bool r0 = y0 >= wy && y0 < wy + subsX, r1 = y0 + 1 >= wy && y0 + 1 < wy + subsX;
-                for (int mx = xlo; mx < xhi; ++mx) {
-                    const int wx = startX + 2 * mx;
-                    const bool c0 = x0 >= wx && x0 < wx + subsX, c1 = x0 + 1 >= wx && x0 + 1 < wx + subsX;
-                    const size_t o = obase + (size_t)(my * outputsX + mx) * N + n;
-                    const float4 a = VV::ld(maxActs + o), g = VV::ld(maxGrads + o);
-                    if (r0 && c0) p00 = vadd(p00, veqmul(i00, a, g));
-                    if (r0 && c1) p01 = vadd(p01, veqmul(i01, a, g));
-                    if (r1 && c0) p10 = vadd(p10, veqmul(i10, a, g));
-                    if (r1 && c1) p11 = vadd(p11, veqmul(i11, a, g));
+            // at most 2 x 2 windows touch the block (subsX <= 4, stride 2): all eight loads go out before the first use,
+            // an absent window reads the channel's first output and contributes through a zero gradient
+            const int ny = yhi - ylo, nx = xhi - xlo;
+            float4 a[2][2], g[2][2];
+#pragma unroll
+            for (int ky = 0; ky < 2; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 2; ++kx) {
+                    const bool ok = ky < ny && kx < nx;
+                    const size_t o = obase + (ok ? (size_t)((ylo + ky) * outputsX + xlo + kx) * N : (size_t)0) + n;
+                    a[ky][kx] = VV::ld(maxActs + o);
+                    g[ky][kx] = VV::ld(maxGrads + o);
+                    if (!ok) g[ky][kx] = z;
+                }
+#pragma unroll
+            for (int ky = 0; ky < 2; ++ky) {
+                const int wy = startX + 2 * (ylo + ky);
+                const bool r0 = ky < ny && y0 >= wy && y0 < wy + subsX, r1 = ky < ny && y0 + 1 >= wy && y0 + 1 < wy + subsX;
+#pragma unroll
+                for (int kx = 0; kx < 2; ++kx) {
+                    const int wx = startX + 2 * (xlo + kx);
+                    const bool c0 = kx < nx && x0 >= wx && x0 < wx + subsX, c1 = kx < nx && x0 + 1 >= wx && x0 + 1 < wx + subsX;
+                    if (r0 && c0) p00 = vadd(p00, veqmul(i00, a[ky][kx], g[ky][kx]));
+                    if (r0 && c1) p01 = vadd(p01, veqmul(i01, a[ky][kx], g[ky][kx]));
+                    if (r1 && c0) p10 = vadd(p10, veqmul(i10, a[ky][kx], g[ky][kx]));
+                    if (r1 && c1) p11 = vadd(p11, veqmul(i11, a[ky][kx], g[ky][kx]));
                 }
             }
             if (RELU) { p00 = vposmask(i00, p00); p01 = vposmask(i01, p01); p10 = vposmask(i10, p10); p11 = vposmask(i11, p11); }
@@ -632,6 +693,15 @@ int mc_conv_local_pool(const float* images, float* target, int numImages, int nu
         dim3 g2(outputsX * outputsX, numFilters, 1);
         if (pooler == MC_POOL_MAX) hipLaunchKernelGGL(k_pool_bigwin<true>, g2, dim3(256), 0, S(s), images, target, numImages, imgSize, subsX, startX, strideX, outputsX, lx);
         else hipLaunchKernelGGL(k_pool_bigwin<false>, g2, dim3(256), 0, S(s), images, target, numImages, imgSize, subsX, startX, strideX, outputsX, lx);
+        return launch_status("mc_conv_local_pool");
+    }
+    if (v && numFilters <= 65535 && (subsX == 2 || subsX == 3)) {
+        dim3 g2;
+        const Map2D mp = make_map2d(numImages, outputsX, outputsX, numFilters, g2);
+#define MC_PF(MAXP, SZ) hipLaunchKernelGGL((k_pool_fix<MAXP, SZ>), g2, dim3(256), 0, S(s), images, target, numImages, imgSize, startX, strideX, outputsX, mp)
+        if (pooler == MC_POOL_MAX) { if (subsX == 2) MC_PF(true, 2); else MC_PF(true, 3); }
+        else { if (subsX == 2) MC_PF(false, 2); else MC_PF(false, 3); }
+#undef MC_PF
         return launch_status("mc_conv_local_pool");
     }
     if (v && numFilters <= 65535) {
