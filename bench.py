@@ -11,8 +11,12 @@ uploaded by the warm-up startBatch; timed steps re-run resident minibatches).  P
 
 The `roofline` object is the dominant kernel, conv2's forward contraction (30.2 GFLOP of the
 167.1 GFLOP step): its launches inside the timed region are bracketed by HIP events on the
-runtime's compute stream.  `cpu_baseline` is the CPU oracle (oracle/golden_net.py, OpenMP C +
-NumPy) timed on one 128-image step on this host's cores (rank 0, N = 1 only).
+runtime's compute stream.  An extra, untimed pass with every launch bracketed by events gives
+`roofline_worst` (the contraction furthest below the fp32-MFMA peak among those that matter: >= 1 % of
+the step), `roofline_hbm` (the HBM-bound kernel that takes the most time, bytes per SURVEY 8d over its
+in-net event time) and `kernels` (every launch over 1 % of the step with its fraction of its roofline).
+`cpu_baseline` is the CPU oracle (oracle/golden_net.py, OpenMP C + NumPy) timed on one 128-image step
+on this host's cores (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -73,7 +77,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    libkernel.setProfile("conv2/fwd:mc_conv_filter_acts_fused")
+    libkernel.setProfile("conv2/fwd:mc_conv_filter_acts_relu_bits")
     barrier()
     t0 = time.perf_counter()
     libkernel.startResident(0, a.warmup % nres, a.steps)
@@ -88,32 +92,54 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
 
-    # optional full per-kernel table (extra, untimed pass; every rank takes part in its collectives)
-    table = None
-    if a.kernel_table:
-        libkernel.setProfile("*")
-        libkernel.startResident(0, 0, 10)
-        libkernel.finishBatch()
-        table = libkernel.getProfile()
-        libkernel.setProfile("")
+    # full per-kernel table (extra, untimed pass; every rank takes part in its collectives)
+    libkernel.setProfile("*")
+    libkernel.startResident(0, 0, 10)
+    libkernel.finishBatch()
+    table = libkernel.getProfile()
+    libkernel.setProfile("")
 
     if rank != 0:
         return
-    if table is not None:
-        rows = sorted(((k, n, ms / n) for k, (n, ms) in table.items()), key=lambda r: -r[2] * r[1])
+    import rooflines
+    import mckernels
+    rows = rooflines.attribute(table, rooflines.step_work(layers, MB))
+    if a.kernel_table:
+        alls = sorted(((k, n, ms / n) for k, (n, ms) in table.items()), key=lambda r: -r[2] * r[1])
+        byk = dict((r["kernel"], r) for r in rows)
         with open(a.kernel_table, "w") as f:
-            json.dump([{"kernel": k, "launches_per_step": n / 10.0, "avg_ms": ms} for k, n, ms in rows], f, indent=1)
+            json.dump([dict({"kernel": k, "launches_per_step": n / 10.0, "avg_ms": ms},
+                            **({"bound": byk[k]["bound"], "achieved": byk[k]["achieved"], "unit": byk[k]["unit"], "frac_of_peak": byk[k]["frac"]} if k in byk else {}))
+                       for k, n, ms in alls], f, indent=1)
+    step_us = dt / a.steps * 1e6
+    brief = lambda r: {"kernel": r["kernel"], "bound": r["bound"], "achieved": round(r["achieved"], 2), "peak": r["peak"], "unit": r["unit"],
+                       "frac": round(r["frac"], 4), "avg_launch_us": round(r["avg_us"], 2), "share_of_step": round(r["avg_us"] / step_us, 4)}
+    big = [r for r in rows if r["avg_us"] >= 0.01 * step_us]
+    mf = [r for r in big if r["bound"] == "mfma"]
+    hb = [r for r in big if r["bound"] == "hbm"]
+    worst = min(mf, key=lambda r: r["frac"]) if mf else None
+    hbm_dom = max(hb, key=lambda r: r["avg_us"]) if hb else None
 
-    # HBM traffic of the same launch: PMC counters cannot be read from inside this process, so the
-    # value is the one measured by the separate rocprofv3 --pmc passes (tools/profile_round.sh) and
-    # committed under profiles/ together with the counter summaries it comes from.
-    traffic = None
+    # HBM traffic of the conv2 forward launch: PMC counters cannot be read from inside this process, so the value is
+    # the one measured by the separate rocprofv3 --pmc passes (tools/profile_round.sh) and committed under profiles/
+    # with the counter summaries it comes from.  It is only reported while the kernel this run timed IS the kernel
+    # those passes saw: the library describes the instantiation + grid it launches for conv2's shape right now
+    # (mc_describe_conv_filter_acts: the autotuner's choice of this process) and that must equal the recorded one.
+    traffic, traffic_note = None, None
+    buf = __import__("ctypes").create_string_buffer(256)
+    mckernels.call("mc_describe_conv_filter_acts", buf, 256, 1, MB, 96, 16, 16, 192, 5, -2, 1, 16, 16, 1)
+    launched = buf.value.decode()
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            traffic = json.load(f)["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
-    n_launch, total_ms = prof.get("conv2/fwd:mc_conv_filter_acts_fused", (0, 0.0))
+            pmc = json.load(f)
+        if pmc.get("launch") == launched:
+            traffic = pmc["hbm_bytes_per_launch"]
+        else:
+            traffic_note = "STALE profiles/pmc_traffic.json: counters were collected on [%s], this run launched [%s]" % (pmc.get("launch"), launched)
+            sys.stderr.write("bench.py: " + traffic_note + " -- roofline.traffic withheld; re-run tools/profile_round.sh\n")
+    except (OSError, KeyError, ValueError) as e:
+        traffic_note = "profiles/pmc_traffic.json unreadable: %s" % e
+    n_launch, total_ms = prof.get("conv2/fwd:mc_conv_filter_acts_relu_bits", (0, 0.0))
     avg_ms = total_ms / max(n_launch, 1)
     achieved = CONV2_FLOPS / (avg_ms * 1e-3) / 1e12 if n_launch else None
     out = {
@@ -128,8 +154,13 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "conv2 forward (mc_igemm, implicit GEMM 192 x 32768 x 2400)", "achieved": achieved,
                      "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": (achieved / (FP32_MFMA_PEAK / 1e12)) if achieved else None,
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/pmc_traffic.json)",
-                     "algorithmic_bytes": CONV2_BYTES, "avg_launch_ms": avg_ms, "launches_timed": n_launch},
+                     "algorithmic_bytes": CONV2_BYTES, "avg_launch_ms": avg_ms, "launches_timed": n_launch, "launch": launched},
+        "roofline_worst": brief(worst) if worst else None,
+        "roofline_hbm": dict(brief(hbm_dom), frac_of_copy_ceiling=round(hbm_dom["achieved"] * 1e9 / rooflines.HBM_COPY, 4)) if hbm_dom else None,
+        "kernels": [brief(r) for r in sorted(big, key=lambda r: -r["avg_us"])],
     }
+    if traffic_note:
+        out["roofline"]["traffic_note"] = traffic_note
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(modelutil)
     print(json.dumps(out))

@@ -41,6 +41,8 @@ int conv_weight_acts_impl(const float*, const float*, float*, int, int, int, int
                           float, float, hipStream_t);
 int conv_weight_grad_plan(int, int, int, int, int, int, int*);
 void set_tune_inhibit(bool);
+void set_describe(char*, int);
+bool describing();
 int gemm_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, float, float, const float*, int,
               const float*, int, int, long, unsigned*, const unsigned*, hipStream_t);
 
@@ -344,12 +346,13 @@ static int conv_fwd_entry(const float* images, const float* filters, float* targ
         const long cols = (long)numModulesY * numModulesX * numImages;
         int kc = 0;
         const int chunks = conv_split_plan(numFilters / numGroups, cols, numImgColors / numGroups * filterSize * filterSize, numGroups, &kc);
-        float* slabs = chunks > 1 ? split_scratch((size_t)chunks * numFilters * cols * sizeof(float), S(s)) : nullptr;
+        static float describeOnly[4];
+        float* slabs = chunks > 1 ? (describing() ? describeOnly : split_scratch((size_t)chunks * numFilters * cols * sizeof(float), S(s))) : nullptr;
         if (slabs) {
             int rc = conv_filter_acts_impl(images, filters, targets, nullptr, MC_NEURON_NONE, numImages, numImgColors, imgSizeY, imgSizeX,
                                            numFilters, filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 0,
                                            0.f, 1.f, slabs, kc, nullptr, S(s));
-            if (rc) return rc;
+            if (rc || describing()) return rc;
             if (reluBits) {
                 if (cols % 4 == 0 && aligned16(targets) && aligned16(slabs)) {
                     const long tiles = (long)ceil_div(numFilters, 32) * ceil_div(cols, 128);
@@ -503,6 +506,22 @@ int mc_gemm_relu_grad(const float* A, const float* B, float* C, int m, int n, in
     MC_REQUIRE(reluActs, "mc_gemm_relu_grad: null reluActs");
     return gemm_entry("mc_gemm_relu_grad", A, B, C, m, n, k, transA, transB, lda, ldb, ldc, scaleTargets, scaleOutput, nullptr,
                       MC_NEURON_NONE, reluActs, ldr, workspace, workspaceBytes, s);
+}
+
+// Dry run: the kernel instantiation and grid mc_conv_filter_acts_fused / _relu_bits would launch for this shape right now (the
+// autotuner's cached choice if the shape has been tuned in this process, else the static rule's).  Launches nothing.
+int mc_describe_conv_filter_acts(char* out, int outLen, int reluBits, int numImages, int numImgColors, int imgSizeY, int imgSizeX,
+                                 int numFilters, int filterSize, int paddingStart, int moduleStride, int numModulesY, int numModulesX,
+                                 int numGroups) {
+    MC_REQUIRE(out && outLen > 0, "mc_describe_conv_filter_acts: no output buffer");
+    out[0] = 0;
+    static float dummy[4];   // never dereferenced: nothing is launched
+    set_describe(out, outLen);
+    const int rc = conv_fwd_entry(dummy, dummy, dummy, nullptr, reluBits ? MC_NEURON_RELU : MC_NEURON_NONE, numImages, numImgColors, imgSizeY, imgSizeX,
+                                  numFilters, filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 0.f, 1.f,
+                                  reluBits ? reinterpret_cast<unsigned*>(dummy) : nullptr, nullptr);
+    set_describe(nullptr, 0);
+    return rc;
 }
 
 size_t mc_relu_bits_words(int rows, int ld) { return rows > 0 && ld > 0 ? (size_t)((rows + 31) / 32) * ld : 0; }

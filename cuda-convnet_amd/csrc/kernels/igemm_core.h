@@ -56,6 +56,8 @@ static __device__ unsigned long long g_stamp[8192 * 8];   // one array per trans
 
 namespace mc {
 extern thread_local bool g_tuneInhibit;   // defined in igemm_fwd.hip; see set_tune_inhibit
+extern thread_local char* g_describeBuf;  // when set, launch_cfg describes the launch it would make here instead of making it
+extern thread_local int g_describeLen;
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -141,6 +143,7 @@ struct MatP {
 
 // stored (K, R): element (k, x) at k*ld + x
 struct MatNatAddr {
+    static const char* tag() { return "MatNatAddr"; }
     typedef MatP P;
     static constexpr bool KC = false;
     __device__ static __forceinline__ bool addr(const P& p, const ConvG&, int g, int b, int k, int x, int& off) {
@@ -151,6 +154,7 @@ struct MatNatAddr {
 };
 // stored (R, K): element (k, x) at x*ld + k
 struct MatKcAddr {
+    static const char* tag() { return "MatKcAddr"; }
     typedef MatP P;
     static constexpr bool KC = true;
     __device__ static __forceinline__ bool addr(const P& p, const ConvG&, int g, int b, int k, int x, int& off) {
@@ -182,6 +186,7 @@ __device__ __forceinline__ bool patch_addr(const ConvG& cg, int g, int kc, int m
 
 // forward B operand: k = filter tap, x = column (m*N + n); NAT (n contiguous)
 struct PatchNatAddr {
+    static const char* tag() { return "PatchNatAddr"; }
     typedef ConvP P;
     static constexpr bool KC = false;
     __device__ static __forceinline__ bool addr(const P& p, const ConvG& cg, int g, int b, int k, int x, int& off) {
@@ -193,6 +198,7 @@ struct PatchNatAddr {
 };
 // weight-gradient A operand: x = filter tap (row), k = (m*N + n); KC (n contiguous)
 struct PatchKcAddr {
+    static const char* tag() { return "PatchKcAddr"; }
     typedef ConvP P;
     static constexpr bool KC = true;
     // When a K tile (k = module * N + image) never straddles two modules, everything that depends on the module
@@ -228,6 +234,7 @@ struct PatchKcAddr {
 };
 // bwd-data B operand: k = (p, fl) (filter pixel, filter within group), x = (pixel*N + n); NAT
 struct HidNatAddr {
+    static const char* tag() { return "HidNatAddr"; }
     typedef ConvP P;
     static constexpr bool KC = false;
     __device__ static __forceinline__ bool addr(const P& p, const ConvG& cg, int g, int b, int k, int x, int& off) {
@@ -257,6 +264,7 @@ struct HidNatAddr {
 // division at all, 24-bit multiplies, range checks as unsigned compares -- the gather address arithmetic is what
 // bounds the producer waves of the backward-data product
 struct HidNatS1Addr {
+    static const char* tag() { return "HidNatS1Addr"; }
     typedef ConvP P;
     static constexpr bool KC = false;
     __device__ static __forceinline__ bool addr(const P& p, const ConvG& cg, int g, int b, int k, int x, int& off) {
@@ -277,6 +285,7 @@ struct HidNatS1Addr {
 };
 // bwd-data A operand: x = channel within group (row), k = (p, fl); filters[(x*fp + p)*F + g*fpg + fl]; KC
 struct FiltTAddr {
+    static const char* tag() { return "FiltTAddr"; }
     typedef ConvP P;
     static constexpr bool KC = true;
     __device__ static __forceinline__ bool addr(const P& p, const ConvG& cg, int g, int b, int k, int x, int& off) {
@@ -435,13 +444,20 @@ __device__ __forceinline__ void lds_done_barrier() {
 // ---------------------------------------------------------------------------------
 // (Asking for more resident workgroups per CU through __launch_bounds__' second argument was measured: the
 // register cap spills in the k-contiguous loaders and no shape gets faster.)
-template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC, int NS, int EPI>
+// KQ = 2: the four consumer waves are WM x WN = 2 wave tiles x 2 halves of every K step (wave (w, kq) multiplies slabs
+// [kq * SLABS / 2, (kq + 1) * SLABS / 2) of each LDS tile); at the end of the tile the kq = 1 waves hand their accumulators
+// over through LDS and the kq = 0 waves add and store.  That makes a 96 x 192 workgroup tile possible (two 96 x 96 wave
+// tiles), which fits the dense / conv weight gradients with 75-192 rows and 160-192 columns that every 4-tile shape pads by
+// 25-40 %.  The sum of an output element is (first halves of all K steps) + (second halves): a fixed order, but not the order
+// of the KQ = 1 tiles, so this tile is selected by rule only (a pure function of the shape), never by the timing autotuner.
+template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC, int NS, int EPI, int KQ>
 __global__ void __launch_bounds__(2 * THREADS)
 #ifndef MC_NO_T51_CAP   // the 160-row tile sits 3-17 registers above 128 = two resident workgroups per CU: cap it (a few spills outside the K loop)
 __attribute__((amdgpu_waves_per_eu((MT == 5 && NT == 1) ? 4 : 1)))
 #endif
 mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
-    static_assert(WM * WN == 4, "4 consumer waves");
+    static_assert(WM * WN * KQ == 4 && (KQ == 1 || KQ == 2), "4 consumer waves");
+    static_assert(KQ == 1 || EPI == EPI_PLAIN, "the K-split tile has the plain epilogue only");
     static_assert(NS >= 2, "at least two tile register sets");
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     typedef Loader<AADDR, BM, BK, VEC> LA;
@@ -588,7 +604,8 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l31 = lane & 31;
-    const int wm = wave / WN, wn = wave % WN;
+    const int kq = wave / (WM * WN), w2 = wave - kq * (WM * WN);
+    const int wm = w2 / WN, wn = w2 % WN;
 
     f32x16 acc[MT][NT];
 
@@ -596,18 +613,18 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     // MFMA k-step (2 k values: lane half h supplies k = kof(s) + h-dependent offset).  The reads of slab
     // s+PF are issued before the MFMAs of slab s; the last PF slabs of a K step prefetch the first PF
     // slabs of the NEXT stage, so the matrix pipe does not drain at the barrier.
-    constexpr int SLABS = BK / 2, PF = 2;
-    static_assert(SLABS >= 4 + PF, "prefetch into consumed fragment registers");
+    constexpr int SLABS = BK / 2 / KQ, PF = 2;   // slabs of a K step this wave multiplies (its half when KQ == 2)
+    static_assert(SLABS >= 4 + PF && SLABS % 4 == 0, "prefetch into consumed fragment registers");
     float af[SLABS][MT], bf[SLABS][NT];
     auto load_slab = [&](const float* cA, const float* cB, int s_) {
-        // slab s_ = (k8, e): k = k8*8 + 4*h + e.  NAT operands read one float per slab; KC
+        // slab s_ (of this wave's part of the tile) = (k8, e): k = k8*8 + 4*h + e.  NAT operands read one float per slab; KC
         // operands fetch the four slabs of a k8 group with one ds_read_b128 when e == 0.
-        const int k8 = s_ >> 2, e = s_ & 3;
+        const int k8 = (s_ >> 2) + kq * (SLABS / 4), e = s_ & 3;
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
             const int row = (wm * MT + a) * 32 + l31;
             if (LA::KC) {
-                if (MT >= 5) {   // tall wave tiles: two b64 reads per k8 group halve the fragment registers in flight
+                if (MT >= 5 || KQ == 2) {   // tall / 3x3 wave tiles: two b64 reads per k8 group halve the fragment registers in flight
                     if ((e & 1) == 0) {
                         const float2 v = reinterpret_cast<const float2*>(cA)[((k8 * 2 + h) * LA::ROWSP + row) * 2 + (e >> 1)];
                         af[s_][a] = v.x; af[s_ + 1][a] = v.y;
@@ -624,7 +641,12 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         for (int b = 0; b < NT; ++b) {
             const int col = (wn * NT + b) * 32 + l31;
             if (LB::KC) {
-                if (e == 0) {
+                if (KQ == 2) {
+                    if ((e & 1) == 0) {
+                        const float2 v = reinterpret_cast<const float2*>(cB)[((k8 * 2 + h) * LB::ROWSP + col) * 2 + (e >> 1)];
+                        bf[s_][b] = v.x; bf[s_ + 1][b] = v.y;
+                    }
+                } else if (e == 0) {
                     const float4 v = reinterpret_cast<const float4*>(cB)[(k8 * 2 + h) * LB::ROWSP + col];
                     bf[s_][b] = v.x; bf[s_ + 1][b] = v.y; bf[s_ + 2][b] = v.z; bf[s_ + 3][b] = v.w;
                 }
@@ -799,6 +821,32 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
 #endif
         stage = nstage;
     }
+    if constexpr (KQ == 2) {
+        // One tile per workgroup (launch_cfg), so after the last K step's barrier the producers are gone and the three stages
+        // are free: the kq = 1 waves park their accumulators there, lane-major (conflict-free), the kq = 0 waves add them.
+        // (A barrier counts only the waves that have not ended.)
+        float* red = smem + (size_t)w2 * (MT * NT * 16 * 64);
+        static_assert((size_t)WM * WN * MT * NT * 16 * 64 <= (size_t)3 * STAGE, "accumulator hand-over must fit the stages");
+        if (kq == 1) {
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((a * NT + b) * 16 + r) * 64 + lane] = acc[a][b][r];
+        }
+        lds_done_barrier();
+        if (kq == 1) return;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                __builtin_amdgcn_sched_barrier(0);   // a block at a time: hoisted together the 144 reads need 144 more registers
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] += red[((a * NT + b) * 16 + r) * 64 + lane];
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // this tile's K loop is complete: store it while the producers run ahead into the next tile
     STAMP(s0);
     store_tile(coff + col_block(ct) * BN);
@@ -820,7 +868,7 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
 // ---------------------------------------------------------------------------------
 // Host-side launch helpers
 // ---------------------------------------------------------------------------------
-template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC, int EPI, int NS = MC_NS>
+template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC, int EPI, int NS = MC_NS, int KQ = 1>
 int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const ConvG& cg, const Dims& d0,
                const Epi& ep, int chunks, hipStream_t st) {
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
@@ -828,7 +876,7 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
     typedef Loader<BADDR, BN, BK, VEC> LB;
     constexpr size_t lds = (3 * (LA::LDS_FLOATS + LB::LDS_FLOATS) + BM) * sizeof(float);   // three stages + the tile's bias column
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = mc_igemm<AADDR, BADDR, MT, NT, WM, WN, BK, VEC, NS, EPI>;
+    auto kern = mc_igemm<AADDR, BADDR, MT, NT, WM, WN, BK, VEC, NS, EPI, KQ>;
     Dims d = d0;
     // per-device state of this instantiation (a function attribute belongs to the device's own code object)
     static std::atomic<unsigned long long> attrDone{0};
@@ -846,7 +894,7 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
     // running its tiles as one pipeline (see the kernel) instead of paying the pipeline fill per tile.
     const int stepsPerTile = ceil_div(d.kChunk < d.Kg ? d.kChunk : d.Kg, BK);
     static const bool nopersist = getenv("MC_IGEMM_NOPERSIST") != nullptr;
-    if (!nopersist && stepsPerTile <= 24 && (long)grid.x * grid.y * grid.z > 2L * num_cus()) {
+    if (KQ == 1 && !nopersist && stepsPerTile <= 24 && (long)grid.x * grid.y * grid.z > 2L * num_cus()) {
         int pc = perCU[dev].load(std::memory_order_relaxed);
         if (pc == 0) {
             int nb = 0;
@@ -859,6 +907,11 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
     }
     static const bool noswz = getenv("MC_IGEMM_NOSWZ") != nullptr;
     d.xcdSwizzle = (d.colTiles % 8 == 0 && grid.x % 8 == 0 && d.colTiles >= 16 && !noswz) ? 1 : 0;
+    if (g_describeBuf) {   // dry run (mc_describe_*): which instantiation and grid this shape gets right now
+        snprintf(g_describeBuf, (size_t)g_describeLen, "mc_igemm<%s, %s, %d, %d, %d, %d, %d, %d, %d, %d, %d> grid=(%u,%u,%u) tile %dx%d", AADDR::tag(),
+                 BADDR::tag(), MT, NT, WM, WN, BK, VEC, NS, EPI, KQ, grid.x, grid.y, grid.z, BM, BN);
+        return MC_OK;
+    }
     hipLaunchKernelGGL(kern, grid, dim3(2 * THREADS), lds, st, pa, pb, cg, d, ep);
     return launch_status("mc_igemm");
 }
@@ -873,8 +926,8 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
 // MC_IGEMM_AUTOTUNE=0, report with =2).  Every tile adds the k terms of an output element in the same
 // order, so the choice never changes a result bit; the split-K chunk count, which would, is not tuned.
 // ---------------------------------------------------------------------------------
-enum { T11, T21, T31, T51, T23, T32, T14, T24, NTILES };
-static const char* const kTileName[NTILES] = {"32x128", "64x128", "96x128", "160x128", "128x192", "192x128", "128x32", "128x64"};
+enum { T11, T21, T31, T51, T23, T32, T14, T24, NTILES, T33K = NTILES };   // NTILES: the tiles the autotuner may pick among
+static const char* const kTileName[NTILES + 1] = {"32x128", "64x128", "96x128", "160x128", "128x192", "192x128", "128x32", "128x64", "96x192k2"};
 
 template <class AADDR, class BADDR, int BK, int VEC, int EPI>
 int launch_tile(int tile, const typename AADDR::P& pa, const typename BADDR::P& pb, const ConvG& cg, const Dims& d, const Epi& ep,
@@ -890,6 +943,10 @@ int launch_tile(int tile, const typename AADDR::P& pa, const typename BADDR::P& 
         case T24: return launch_cfg<AADDR, BADDR, 2, 1, 2, 2, BK, VEC, EPI>(pa, pb, cg, d, ep, chunks, st);   // 2x2 waves, 64 columns
         default: break;
     }
+#ifdef MC_IGEMM_KQ_TILE   // see heuristic_tile: measured slower than the padded 4-tile shapes, not built by default
+    if constexpr (BK == 32 && EPI == EPI_PLAIN)   // the K-split tile: long-k products (weight gradients) only
+        if (tile == T33K) return launch_cfg<AADDR, BADDR, 3, 3, 1, 2, BK, VEC, EPI, MC_NS, 2>(pa, pb, cg, d, ep, chunks, st);
+#endif
     if constexpr (EPI != EPI_SLOW) {
         switch (tile) {
             case T51: return launch_cfg<AADDR, BADDR, 5, 1, 1, 4, BK, VEC, EPI>(pa, pb, cg, d, ep, chunks, st);
@@ -905,7 +962,25 @@ int launch_tile(int tile, const typename AADDR::P& pa, const typename BADDR::P& 
 // strip per consumer wave) win almost everywhere; exactly 160 rows (NIN cccp1 / cccp2) take one 160-row tile so
 // the big operand is read once; 192-column tiles (2x2 waves, 3 strips each) when they cut the padding of the
 // column extent (F = 192 weight gradients: 256 -> 192).
-inline int heuristic_tile(const Dims& d, int chunks) {
+static const int kRowsOf[NTILES + 1] = {32, 64, 96, 160, 128, 192, 128, 128, 96}, kColsOf[NTILES + 1] = {128, 128, 128, 128, 192, 128, 32, 64, 192};
+inline int heuristic_tile4(const Dims& d, int chunks);
+// kqOk: the call site has the 96 x 192 K-split tile (long-k products).  It is taken when it cuts the padded work of the
+// 4-tile rule's pick by 15 % or more -- decided from the extents alone, see the kernel's comment.
+inline int heuristic_tile(const Dims& d, int chunks, bool kqOk = false) {
+    const int t = heuristic_tile4(d, chunks);
+#ifndef MC_IGEMM_KQ_TILE
+    // Measured on MI355X (NIN weight gradients, tools/build_variant.sh kq -DMC_IGEMM_KQ_TILE): the tile removes the padding
+    // (cccp1 160 x 192: 62 % -> 83 % useful MFMA work) but is no faster -- cccp1 112 -> 112 us, cccp2 64 -> 106, conv1 69 -> 78,
+    // cccp3 43 -> 50: these products are bound by their k-contiguous loaders (128 bytes a row and K step from 288-320 rows
+    // 512 KB apart) and one resident workgroup per CU, not by the matrix pipe.  Kept as a build option, off by default.
+    return t;
+#endif
+    static const bool nokq = getenv("MC_IGEMM_NOKQ") != nullptr;
+    if (!kqOk || nokq || d.batches != 1 || d.Ng <= 64) return t;
+    auto padded = [&](int tile) { return (double)ceil_div(d.Mg, kRowsOf[tile]) * kRowsOf[tile] * ceil_div(d.Ng, kColsOf[tile]) * kColsOf[tile]; };
+    return padded(T33K) <= 0.85 * padded(t) ? (int)T33K : t;
+}
+inline int heuristic_tile4(const Dims& d, int chunks) {
     const long z = (long)chunks * d.groups * d.batches;
     const int mt32 = ceil_div(d.Mg, 32);
     const long colTiles = ceil_div(d.Ng, 128);
@@ -934,11 +1009,12 @@ int launch_rows_cols_epi(const typename AADDR::P& pa, const typename BADDR::P& p
     // tuning knob (benchmarks only): MC_IGEMM_TILE="MT,NT" forces the wave tile
     static const char* forced = getenv("MC_IGEMM_TILE");
     if (forced && forced[0] && forced[1] == ',') {
-        static const int map[8][3] = {{1, 1, T11}, {2, 1, T21}, {3, 1, T31}, {5, 1, T51}, {2, 3, T23}, {3, 2, T32}, {4, 0, T14}, {4, 1, T24}};
+        static const int map[9][3] = {{1, 1, T11}, {2, 1, T21}, {3, 1, T31}, {5, 1, T51}, {2, 3, T23}, {3, 2, T32}, {4, 0, T14}, {4, 1, T24}, {3, 3, T33K}};
         for (auto& m : map)
             if (forced[0] - '0' == m[0] && forced[2] - '0' == m[1]) return launch_tile<AADDR, BADDR, BK, VEC, EPI>(m[2], pa, pb, cg, d, ep, chunks, st);
     }
-    const int rule = heuristic_tile(d, chunks);
+    const int rule = heuristic_tile(d, chunks, BK == 32 && EPI == EPI_PLAIN);
+    if (rule == T33K) return launch_tile<AADDR, BADDR, BK, VEC, EPI>(rule, pa, pb, cg, d, ep, chunks, st);   // by rule only: its sum order is its own
     static const char* at = getenv("MC_IGEMM_AUTOTUNE");
     static const int mode = at ? atoi(at) : 1;
     if (mode == 0) return launch_tile<AADDR, BADDR, BK, VEC, EPI>(rule, pa, pb, cg, d, ep, chunks, st);
@@ -958,7 +1034,7 @@ int launch_rows_cols_epi(const typename AADDR::P& pa, const typename BADDR::P& p
     }
     // an accumulating call (scaleTargets != 0) is not idempotent: serve it by the rule and let a later plain call tune;
     // so is a call from an entry point that must not create events or block (mc_conv_weight_grad_noalloc)
-    if (EPI == EPI_SLOW || ep.beta != 0.f || g_tuneInhibit) return launch_tile<AADDR, BADDR, BK, VEC, EPI>(rule, pa, pb, cg, d, ep, chunks, st);
+    if (EPI == EPI_SLOW || ep.beta != 0.f || g_tuneInhibit || g_describeBuf) return launch_tile<AADDR, BADDR, BK, VEC, EPI>(rule, pa, pb, cg, d, ep, chunks, st);
 
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
@@ -968,8 +1044,7 @@ int launch_rows_cols_epi(const typename AADDR::P& pa, const typename BADDR::P& p
     for (int t = 0; t < NTILES; ++t) {
         ms[t] = -1.f;
         // skip tiles that would compute more than 4x the needed rows (a 160-row tile for a 10-row product)
-        static const int rowsOf[NTILES] = {32, 64, 96, 160, 128, 192, 128, 128};
-        if (t != rule && (long)ceil_div(d.Mg, rowsOf[t]) * rowsOf[t] > 4L * ((d.Mg + 31) / 32 * 32)) continue;
+        if (t != rule && (long)ceil_div(d.Mg, kRowsOf[t]) * kRowsOf[t] > 4L * ((d.Mg + 31) / 32 * 32)) continue;
         if ((t == T14 || t == T24) && d.Ng > 64) continue;   // the narrow tile only where 128 columns are mostly padding
         int rc = launch_tile<AADDR, BADDR, BK, VEC, EPI>(t, pa, pb, cg, d, ep, chunks, st);   // warm (and validates the launch)
         if (rc != MC_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }

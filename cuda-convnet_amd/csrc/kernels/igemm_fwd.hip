@@ -5,6 +5,10 @@ namespace mc {
 MC_STAMP_API(fwd)
 
 thread_local bool g_tuneInhibit = false;
+thread_local char* g_describeBuf = nullptr;
+thread_local int g_describeLen = 0;
+void set_describe(char* buf, int len) { g_describeBuf = buf; g_describeLen = len; }
+bool describing() { return g_describeBuf != nullptr; }
 // While set (per host thread), a shape that has not been tuned yet runs the static rule's tile instead of the timed trial.
 void set_tune_inhibit(bool on) { g_tuneInhibit = on; }
 

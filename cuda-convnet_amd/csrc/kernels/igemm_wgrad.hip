@@ -41,10 +41,9 @@ int conv_weight_grad_plan(int N, int C, int F, int fs, int M, int groups, int* k
     const int rows = (C / groups) * fs * fs, fpg = F / groups;
     const long K = (long)M * N;
     Dims d{rows, fpg, (int)K, (int)K, groups, 0, 0, 1, 0};
-    static const int rowsOf[NTILES] = {32, 64, 96, 160, 128, 192, 128, 128}, colsOf[NTILES] = {128, 128, 128, 128, 192, 128, 32, 64};
     // the tile the static rule would take for a grid that fills the device
-    const int t = heuristic_tile(d, ceil_div(num_cus(), (long)ceil_div(rows, 128) * ceil_div(fpg, 128) * groups));
-    const long tiles = (long)ceil_div(rows, rowsOf[t]) * ceil_div(fpg, colsOf[t]) * groups;
+    const int t = heuristic_tile(d, ceil_div(num_cus(), (long)ceil_div(rows, 128) * ceil_div(fpg, 128) * groups), true);
+    const long tiles = (long)ceil_div(rows, kRowsOf[t]) * ceil_div(fpg, kColsOf[t]) * groups;
     long chunks = num_cus() / tiles;
     if (chunks < 1) chunks = 1;
     long kc = (ceil_div(K, chunks) + MC_BK_KC - 1) / MC_BK_KC * MC_BK_KC;

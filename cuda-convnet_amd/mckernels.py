@@ -78,6 +78,7 @@ _SIGS = {
     "mc_compute_logreg_softmax_grad": [c_fp] * 3 + [c_i, c_f, c_i, c_i, c_fp],
     "mc_weights_update": [c_fp] * 3 + [c_sz, c_f, c_f, c_f, c_fp],
     "mc_weights_update_spans": [c_fp] * 4 + [c_i, c_fp],
+    "mc_describe_conv_filter_acts": [ctypes.c_char_p, c_i, c_i] + [c_i] * 11,
     "mc_device_info": [ctypes.c_char_p, c_i, ctypes.POINTER(c_i)],
 }
 

@@ -129,6 +129,15 @@ size_t mc_conv_split_workspace_bytes(int numImages, int numImgColors, int imgSiz
                                      int numGroups);
 int mc_reserve_conv_split_workspace(size_t bytes, mcStream_t stream);
 
+/* Dry run of mc_conv_filter_acts_fused (reluBits = 0) / mc_conv_filter_acts_relu_bits (reluBits = 1): writes into `out` the
+ * kernel instantiation, grid and workgroup tile the call would launch for this shape right now -- the autotuner's cached
+ * choice if the shape has been tuned in this process, else the static rule's -- and launches nothing.  bench.py uses it to
+ * check that the kernel it timed is the one the committed PMC counters were collected on. */
+int mc_describe_conv_filter_acts(char* out, int outLen, int reluBits, int numImages, int numImgColors,
+                                 int imgSizeY, int imgSizeX, int numFilters, int filterSize,
+                                 int paddingStart, int moduleStride, int numModulesY, int numModulesX,
+                                 int numGroups);
+
 /* A partialSum the library considers a good split of the module axis for this shape on this
  * device (divides numModules; the reference takes it from the layer-def file instead). */
 int mc_conv_weight_acts_pick_partial_sum(int numImages, int numImgColors, int numFilters,
