@@ -15,6 +15,7 @@
 
 namespace rt {
 
+static const size_t kBucketElems = 256 * 1024;   // smallest all-reduce worth a launch of its own: 1 MiB of fp32
 static inline mcStream_t ST() { return reinterpret_cast<mcStream_t>(computeStream()); }
 
 // ==========================================================================================
@@ -218,6 +219,8 @@ void GradComm::allReduceAsync(float* p, size_t n, hipStream_t producer) {
     RT_HIP(hipEventRecord(_ready, producer));
     RT_HIP(hipStreamWaitEvent(_stream, _ready, 0));
     nccl_check(rccl().allReduce(p, p, n, kNcclFloat, kNcclSum, _comm, _stream), "ncclAllReduce");
+    _stats.calls++;
+    _stats.bytes += (double)n * sizeof(float);
     _pending = true;
 }
 
@@ -228,9 +231,31 @@ void GradComm::waitAll(hipStream_t consumer) {
         RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         _events.push_back(e);
     }
+    // how long the compute stream stalls here = what back-propagation did not hide; read back in takeStats()
+    const bool timed = _waitUsed < _waitPairs.size() || _waitPairs.size() < 4096;
+    if (timed && _waitUsed == _waitPairs.size()) {
+        std::pair<hipEvent_t, hipEvent_t> pr;
+        RT_HIP(hipEventCreate(&pr.first));
+        RT_HIP(hipEventCreate(&pr.second));
+        _waitPairs.push_back(pr);
+    }
+    if (timed) RT_HIP(hipEventRecord(_waitPairs[_waitUsed].first, consumer));
     RT_HIP(hipEventRecord(_events[0], _stream));
     RT_HIP(hipStreamWaitEvent(consumer, _events[0], 0));
+    if (timed) RT_HIP(hipEventRecord(_waitPairs[_waitUsed++].second, consumer));
+    _stats.steps++;
     _pending = false;
+}
+
+GradComm::Stats GradComm::takeStats() {
+    for (size_t i = 0; i < _waitUsed; i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, _waitPairs[i].first, _waitPairs[i].second) == hipSuccess) _stats.waitMs += ms;
+    }
+    _waitUsed = 0;
+    Stats out = _stats;
+    _stats = Stats();
+    return out;
 }
 
 // ==========================================================================================
@@ -291,7 +316,7 @@ Layer* ConvNet::initLayer(const std::string& layerType, PyObject* paramsDict) {
         l = pluginLayers()[layerType](this, paramsDict);
     } else {
         throw std::runtime_error("Unknown layer type " + layerType +
-                                 " (eltmax, nailbed, blur, resize, rgb2yuv, rgb2lab are outside this runtime's scope; plugin types need Plugins/*.so)");
+                                 " (plugin types such as cccp and cost.gsinlabel need Plugins/*.so next to libkernel.so)");
     }
     _layers.push_back(l);
     return l;
@@ -312,6 +337,9 @@ void ConvNet::initDevice() {
     RT_HIP(hipStreamCreateWithFlags(&_stream, hipStreamNonBlocking));
     setComputeStream(_stream);
     copyToGPU();
+    size_t split = 0;
+    for (Layer* l : _layers) split = std::max(split, l->splitWorkspaceBytes(_dp->getMinibatchSize()));
+    RT_MC(mc_reserve_conv_split_workspace(split, ST()));
 }
 
 void ConvNet::run() {
@@ -369,10 +397,14 @@ void ConvNet::copyToGPU() {
     }
     for (size_t i = 0; i < order.size(); i++) order[i]->bind(_arenaW + offs[i], _arenaInc + offs[i], _arenaGrad + offs[i], offs[i]);
     _allWeights = order;
-    for (Layer* l : _layers) {
-        WeightLayer* wl = dynamic_cast<WeightLayer*>(l);
-        for (int i = 0; wl && i < wl->getNumWeights(); i++) _sharedWeights |= !wl->getWeights(i).isOwner();
+    std::vector<size_t> ends;
+    std::vector<int> contributors;
+    for (size_t i = 0; i < order.size(); i++) {
+        order[i]->setArenaIndex((int)i);
+        ends.push_back(i + 1 < order.size() ? offs[i + 1] : total);
+        contributors.push_back(order[i]->contributors());
     }
+    _buckets.configure(ends, contributors, kBucketElems);
     for (Layer* l : _layers) l->copyToGPU();
     buildUpdateSpans();
     RT_HIP(hipDeviceSynchronize());
@@ -421,36 +453,23 @@ void ConvNet::fprop(int miniIdx, PASS_TYPE passType) {
 }
 
 void ConvNet::bprop(PASS_TYPE passType) {
-    _bucketLo = _bucketHi = 0;
+    _buckets.beginStep();
     for (CostLayer* c : _costs) c->bprop(passType);
     reset();
     if (_comm.active() && passType == PASS_TRAIN) {
         // whatever has not been sent yet goes now; the update then waits for the side stream
-        flushBuckets(true);
+        size_t lo, hi;
+        if (_buckets.finish(&lo, &hi)) _comm.allReduceAsync(_arenaGrad + lo, hi - lo, _stream);
         _comm.waitAll(_stream);
     }
 }
 
-// Tensors become ready in (roughly) arena order.  Ready tensors are coalesced into buckets of
-// at least kBucketElems and reduced while the rest of back-propagation runs; anything out of
-// order simply waits for the final flush, which reduces the remainder of the arena.
-static const size_t kBucketElems = 256 * 1024;   // 1 MiB of fp32
-
+// A tensor's gradient is complete once every layer that adds into it has queued its product; complete tensors are reduced
+// on the side stream in buckets of >= kBucketElems while the rest of back-propagation runs (buckets.h has the rules).
 void ConvNet::gradientReady(Weights& w) {
-    if (!_comm.active() || _sharedWeights) return;
-    const size_t lo = w.arenaOffset(), hi = lo + (w.numel() + 63) / 64 * 64;
-    if (lo == _bucketHi) {
-        _bucketHi = hi;
-        if (_bucketHi - _bucketLo >= kBucketElems) flushBuckets(false);
-    }
-}
-
-void ConvNet::flushBuckets(bool force) {
-    if (force) _bucketHi = _arenaElems;
-    if (_bucketHi > _bucketLo) {
-        _comm.allReduceAsync(_arenaGrad + _bucketLo, _bucketHi - _bucketLo, _stream);
-        _bucketLo = _bucketHi;
-    }
+    if (!_comm.active() || w.arenaIndex() < 0) return;
+    size_t lo, hi;
+    if (_buckets.arrived((size_t)w.arenaIndex(), &lo, &hi)) _comm.allReduceAsync(_arenaGrad + lo, hi - lo, _stream);
 }
 
 // One launch updates every tensor (spans of <= 4096 elements, built once); tensors that do not
@@ -618,7 +637,10 @@ void TrainingWorker::run() {
     DataProvider& dp = _convNet->getDataProvider();
     dp.setData(*_data);
     _convNet->beginBatchCosts();
+    const long gmb = (long)dp.getMinibatchSize() * _convNet->world();
     for (int i = 0; i < dp.getNumMinibatches(); i++) {
+        // a ragged global tail is dealt out unevenly (dp.shard_columns): its gradient scale is 1 / (its true global size)
+        if (_globalCases > 0) _convNet->setGlobalMinibatchCases((int)std::min(gmb, _globalCases - i * gmb));
         _convNet->fprop(i, _test ? PASS_TEST : PASS_TRAIN);
         _convNet->endMinibatchCosts(dp.getNumCasesInMinibatch(i));
         if (!_test) {
@@ -626,6 +648,7 @@ void TrainingWorker::run() {
             _convNet->updateWeights();
         }
     }
+    _convNet->setGlobalMinibatchCases(0);
     Cost* cost = _convNet->collectCosts();   // synchronises the stream
     dp.clearData();
     _convNet->getResultQueue().enqueue(new WorkResult(WorkResult::BATCH_DONE, cost));

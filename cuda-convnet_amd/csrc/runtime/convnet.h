@@ -3,6 +3,7 @@
 // Python enqueues a Worker, one device thread dequeues and runs it, results come back through
 // a second queue (convnet.cu:149-158, queue.h:84-110).
 #pragma once
+#include "buckets.h"
 #include <condition_variable>
 #include <functional>
 #include <map>
@@ -96,6 +97,10 @@ public:
     void allReduceAsync(float* p, size_t n, hipStream_t producer);   // sum, in place
     void waitAll(hipStream_t consumer);
     void forceSingleRank(bool f) { _forced = f; }   // exercise the RCCL path with world == 1 (tests)
+    // Counters since the last report: all-reduce calls and bytes, steps (waitAll calls), and the time the compute stream
+    // spent blocked on the side stream in waitAll (event pairs around the wait; the caller must have drained the stream).
+    struct Stats { long calls = 0, steps = 0; double bytes = 0, waitMs = 0; };
+    Stats takeStats();
 
 private:
     void* _comm = nullptr;
@@ -103,6 +108,9 @@ private:
     std::vector<hipEvent_t> _events;
     size_t _nextEvent = 0;
     hipEvent_t _ready = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> _waitPairs;   // timed (before, after) the wait, one pair per step
+    size_t _waitUsed = 0;
+    Stats _stats;
     int _rank = 0, _world = 1;
     bool _forced = false, _pending = false;
 };
@@ -154,9 +162,13 @@ public:
     void registerWeights(Weights* w) { _allWeights.push_back(w); }
     void gradientReady(Weights& w);           // called from WeightLayer::bpropCommon
     float* workspace(size_t bytes);
-    int gradScaleCases(int localCases) const { return localCases * _comm.world(); }
+    // the 1/N of the gradient scale: the cases of the GLOBAL minibatch (all ranks).  Ranks hold equal shares except in a ragged
+    // tail, where the driver hands the true global count down (startBatch's third argument); see dp.shard_columns.
+    int gradScaleCases(int localCases) const { return _globalMinibatchCases > 0 ? _globalMinibatchCases : localCases * _comm.world(); }
+    void setGlobalMinibatchCases(int n) { _globalMinibatchCases = n; }
     unsigned long long nextRandOffset(size_t n);
     unsigned long long seed() const { return _seed; }
+    int world() const { return _comm.world(); }
     void setSeed(unsigned long long s) { _seed = s; _randOffset = 0; }
     void releaseHost();
     int deviceID() const { return _deviceID; }
@@ -168,7 +180,6 @@ private:
     void run();
     void initDevice();
     Layer* initLayer(const std::string& layerType, PyObject* paramsDict);
-    void flushBuckets(bool force);
     void buildUpdateSpans();
 
     std::vector<Layer*> _layers;
@@ -185,7 +196,7 @@ private:
     // arenas
     float *_arenaW = nullptr, *_arenaInc = nullptr, *_arenaGrad = nullptr;
     size_t _arenaElems = 0;
-    size_t _bucketLo = 0, _bucketHi = 0;   // [lo, hi) of gradient elements ready but not yet reduced
+    BucketPlanner _buckets;                // which slices of the gradient arena are reduced when (buckets.h)
     mcUpdateSpan* _spans = nullptr;
     int _numSpans = 0;
     float* _workspace = nullptr;
@@ -195,8 +206,8 @@ private:
     std::vector<int> _slotCases;
     double _baseErr = 0;
     int _numTests = 0, _numFailures = 0;
-    bool _sharedWeights = false;   // some matrix has several contributing layers: reduce at the end only
     unsigned long long _seed, _randOffset = 0;
+    int _globalMinibatchCases = 0;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -226,11 +237,13 @@ protected:
 
 class TrainingWorker : public DataWorker {
 public:
-    TrainingWorker(ConvNet& net, HostMatV* data, bool test) : DataWorker(net, data), _test(test) {}
+    // globalCases: cases of this batch over all ranks (0 = local cases x world size)
+    TrainingWorker(ConvNet& net, HostMatV* data, bool test, long globalCases = 0) : DataWorker(net, data), _test(test), _globalCases(globalCases) {}
     void run() override;
 
 private:
     bool _test;
+    long _globalCases;
 };
 
 // Re-runs minibatches of the batch that is already on the device (left there by the previous

@@ -257,12 +257,14 @@ void NeuronLayer::bpropActs(DevMat& v, int, float scaleTargets, PASS_TYPE passTy
 Weights::Weights(HostMat& hW, HostMat& hInc, float eps, float wc, float mom, bool deviceFortran)
     : _hW(&hW), _hInc(&hInc), _eps(eps), _wc(wc), _mom(mom), _devFortran(deviceFortran) {
     if (hW.rows() != hInc.rows() || hW.cols() != hInc.cols()) throw std::runtime_error("weights and weightsInc differ in shape");
+    _contributors = eps > 0 ? 1 : 0;
 }
 
 Weights::Weights(Weights& src, float eps)
     : _hW(nullptr), _hInc(nullptr), _src(&src), _eps(eps), _wc(0), _mom(src.getMom()) {
     _hW = src._hW;
     _hInc = src._hInc;
+    if (eps > 0) const_cast<Weights&>(src.owner())._contributors++;
 }
 
 Weights::~Weights() {
@@ -586,6 +588,16 @@ void LocalLayer::sparseScatter(int i, const DevMat& gathered, DevMat& target, fl
 ConvLayer::ConvLayer(ConvNet* convNet, PyObject* paramsDict) : LocalLayer(convNet, paramsDict) {
     _partialSum = pyDictGetInt(paramsDict, "partialSum");
     _sharedBiases = pyDictGetInt(paramsDict, "sharedBiases") != 0;
+}
+
+size_t ConvLayer::splitWorkspaceBytes(int numCases) const {
+    size_t need = 0;
+    for (size_t i = 0; i < _channels->size(); i++) {
+        const int ch = sparse(i) ? sparseChannels(i) : _channels->at(i);
+        need = std::max(need, mc_conv_split_workspace_bytes(numCases, ch, _imgSize->at(i), _imgSize->at(i), _numFilters, _filterSize->at(i),
+                                                            _modulesX, _modulesX, _groups->at(i)));
+    }
+    return need;
 }
 
 void ConvLayer::fpropActs(int i, float scaleTargets, PASS_TYPE passType) {

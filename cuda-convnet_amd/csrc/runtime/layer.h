@@ -78,6 +78,11 @@ public:
     int getNumUpdates() const { return owner()._numUpdates; }
     int incNumUpdates() { return const_cast<Weights&>(owner())._numUpdates++; }
     size_t arenaOffset() const { return owner()._offset; }
+    // data parallel bookkeeping (buckets.h): position of the owning tensor in the arena order, and how many layers' gradient
+    // products add into it per step (the owner's and those of the layers sharing it, each only if it learns)
+    int arenaIndex() const { return owner()._arenaIndex; }
+    void setArenaIndex(int i) { _arenaIndex = i; }
+    int contributors() const { return owner()._contributors; }
 
     void bind(float* w, float* inc, float* grad, size_t offset);  // arena slices (owner only)
     void copyToGPU();    // owner only; no-op for shared
@@ -97,6 +102,7 @@ private:
     float _eps, _wc, _mom;
     bool _devFortran = false;
     int _numUpdates = 0;
+    int _arenaIndex = -1, _contributors = 0;
 };
 
 class WeightList {
@@ -146,6 +152,10 @@ public:
     // the producer lays the bits out for a (rows, ld) matrix: the layout is tied to that view (32-row blocks), and a conv
     // output (filters, modules * cases) read by an fc layer as (features, cases) is a different one.
     virtual bool readsReluBits(int rows, int ld, int numCases) const { return false; }
+
+    // bytes of library-side split-K workspace this layer's forward / backward-data calls need at `numCases` (0: none); the
+    // net reserves the largest at initModel so that no training step allocates (mc_reserve_conv_split_workspace)
+    virtual size_t splitWorkspaceBytes(int numCases) const { return 0; }
 
     // weight layers override these
     virtual void updateWeights() {}
@@ -277,6 +287,7 @@ protected:
 class ConvLayer : public LocalLayer {
 public:
     ConvLayer(ConvNet* convNet, PyObject* paramsDict);
+    size_t splitWorkspaceBytes(int numCases) const override;
 
 protected:
     void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;

@@ -34,6 +34,14 @@ static std::deque<Worker*> pending;   // work items whose Python references are 
         return nullptr;                                                              \
     }
 
+// Synchronous entry points submit one item and wait for ITS result; the result queue is first-in first-out, so with a
+// startBatch / startResident still outstanding they would swallow that batch's result instead.
+#define REQUIRE_IDLE(what)                                                                                  \
+    if (!pending.empty()) {                                                                                 \
+        PyErr_SetString(PyExc_RuntimeError, what ": a started batch is outstanding (call finishBatch first)"); \
+        return nullptr;                                                                                     \
+    }
+
 static PyObject* fail(const std::exception& e) {
     PyErr_SetString(PyExc_RuntimeError, e.what());
     return nullptr;
@@ -100,9 +108,10 @@ static PyObject* startBatch(PyObject*, PyObject* args) {
     REQUIRE_MODEL();
     PyObject* data;
     int test = 0;
-    if (!PyArg_ParseTuple(args, "O!|i", &PyList_Type, &data, &test)) return nullptr;
+    long globalCases = 0;   // data parallel: cases of this batch over all ranks (optional; 0 = local cases x world size)
+    if (!PyArg_ParseTuple(args, "O!|il", &PyList_Type, &data, &test, &globalCases)) return nullptr;
     try {
-        submit(new TrainingWorker(*model, getMatrixV(data), test != 0));
+        submit(new TrainingWorker(*model, getMatrixV(data), test != 0, globalCases));
     } catch (std::exception& e) { return fail(e); }
     return Py_BuildValue("i", 0);
 }
@@ -168,6 +177,7 @@ static PyObject* checkGradients(PyObject*, PyObject* args) {
     REQUIRE_MODEL();
     PyObject* data;
     if (!PyArg_ParseTuple(args, "O!", &PyList_Type, &data)) return nullptr;
+    REQUIRE_IDLE("checkGradients");
     try {
         submit(new GradCheckWorker(*model, getMatrixV(data)));
     } catch (std::exception& e) { return fail(e); }
@@ -182,6 +192,7 @@ static PyObject* checkGradients(PyObject*, PyObject* args) {
 
 static PyObject* syncWithHost(PyObject*, PyObject*) {
     REQUIRE_MODEL();
+    REQUIRE_IDLE("syncWithHost");
     submit(new SyncWorker(*model));
     WorkResult* res = await_result();
     if (!check(res, WorkResult::SYNC_DONE)) return nullptr;
@@ -191,6 +202,7 @@ static PyObject* syncWithHost(PyObject*, PyObject*) {
 
 // ---- NEW entry points ---------------------------------------------------------------------
 static PyObject* run_on_device(std::function<void()> fn) {
+    REQUIRE_IDLE("this call");
     submit(new CallWorker(*model, fn));
     WorkResult* res = await_result();
     if (!check(res, WorkResult::SYNC_DONE)) return nullptr;
@@ -313,11 +325,20 @@ static PyObject* setProfile(PyObject*, PyObject* args) {
     return run_on_device([=] { profileSetFilter(f.c_str()); });
 }
 
-// getProfile() -> {key: (launches, total_ms)}; clears the records
+// getProfile() -> {key: (launches, total_ms)}; clears the records.  With a data-parallel communicator it also carries the
+// counters since the last call: "dp/allreduce:bytes" -> (all-reduce calls, bytes reduced), "dp/wait:ms" -> (steps,
+// milliseconds the compute stream was blocked waiting for the reductions, i.e. what back-propagation did not hide).
 static PyObject* getProfile(PyObject*, PyObject*) {
     REQUIRE_MODEL();
     std::map<std::string, std::pair<long, double>> rep;
-    PyObject* ok = run_on_device([&] { profileReport(rep, true); });
+    PyObject* ok = run_on_device([&] {
+        profileReport(rep, true);
+        if (model->comm().active()) {
+            const GradComm::Stats st = model->comm().takeStats();
+            rep["dp/allreduce:bytes"] = std::make_pair(st.calls, st.bytes);
+            rep["dp/wait:ms"] = std::make_pair(st.steps, st.waitMs);
+        }
+    });
     if (!ok) return nullptr;
     Py_DECREF(ok);
     PyObject* dict = PyDict_New();

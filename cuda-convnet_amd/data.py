@@ -1,8 +1,14 @@
-"""Data providers (Python 3).  Mirrors the provider protocol of the reference's Python/data.py:
-`get_next_batch()` -> (epoch, batchnum, data), batch ranges that wrap and bump the epoch,
-`get_data_dims(idx)`, `get_num_classes()`, and the type registry with the `dummy-<name>-<dims>`
-convention (Python/data.py:108-124, 275-286).  The JPEG / mat providers of the reference are not
-part of the training hot path (they need PIL and real datasets) and are not provided."""
+"""Data-provider protocol and the file-backed / dummy providers (Python 3).
+
+A provider answers three questions for the driver -- `get_next_batch()` -> (epoch, batchnum, data), `get_data_dims(idx)`,
+`get_num_classes()` -- and is looked up by the `--data-provider` string in one registry (`PROVIDERS`; `dp_types` /
+`dp_classes` are the reference's two views of it, kept because gpumodel / convnet print and extend them).  The on-disk
+format is the reference's (Python/data.py): a directory with `batches.meta` and `data_batch_<n>` pickles (optionally split
+into `data_batch_<n>.1`, `.2`, ... sub-batches), batch numbers that cycle through `batch_range` with the epoch counting the
+wrap-arounds, and `dummy-<kind>-<dims>` type strings that carry the dimensionality in the name.
+
+Out of scope: the reference's JPEG (`jpeg`, `cropped-jpeg`, ...) and `mat` providers -- they need PIL /
+scipy.io datasets that are not part of the training hot path."""
 import os
 import re
 
@@ -18,60 +24,81 @@ class DataProviderException(Exception):
     pass
 
 
+class BatchCursor(object):
+    """Where a provider is in its cycle over `batch_range`: (epoch, batch number), and how to step."""
+
+    def __init__(self, batch_range, epoch=1, batchnum=None):
+        self.order = list(batch_range)
+        self.epoch = epoch
+        self.pos = self.order.index(batchnum) if batchnum in self.order else 0
+
+    @property
+    def batchnum(self):
+        return self.order[self.pos]
+
+    def peek(self):
+        return (self.pos + 1) % len(self.order)
+
+    def step(self):
+        self.pos = self.peek()
+        self.epoch += self.pos == 0       # back at the first batch: a new epoch
+
+
 class DataProvider(object):
     BATCH_REGEX = re.compile(r"^data_batch_(\d+)(\.\d+)?$")
 
     def __init__(self, data_dir, batch_range=None, init_epoch=1, init_batchnum=None, dp_params=None, test=False):
-        if batch_range is None:
-            batch_range = DataProvider.get_batch_nums(data_dir)
-        if init_batchnum is None or init_batchnum not in batch_range:
-            init_batchnum = batch_range[0]
-        self.data_dir = data_dir
-        self.batch_range = list(batch_range)
-        self.curr_epoch = init_epoch
-        self.curr_batchnum = init_batchnum
-        self.dp_params = dp_params or {}
+        self.data_dir, self.test = data_dir, test
+        self.dp_params = {} if dp_params is None else dp_params
+        self._start(DataProvider.get_batch_nums(data_dir) if batch_range is None else batch_range, init_epoch, init_batchnum)
         self.batch_meta = self.get_batch_meta(data_dir)
         self.data_dic = None
-        self.test = test
-        self.batch_idx = self.batch_range.index(init_batchnum)
 
-    # -- iteration -----------------------------------------------------
+    def _start(self, batch_range, epoch=1, batchnum=None):
+        self._cursor = BatchCursor(batch_range, epoch, batchnum)
+        self.batch_range = self._cursor.order
+
+    # the cursor under the reference's attribute names (drivers and checkpoints read these)
+    curr_epoch = property(lambda self: self._cursor.epoch, lambda self, e: setattr(self._cursor, "epoch", e))
+    curr_batchnum = property(lambda self: self._cursor.batchnum, lambda self, b: setattr(self._cursor, "pos", self.batch_range.index(b)))
+    batch_idx = property(lambda self: self._cursor.pos, lambda self, i: setattr(self._cursor, "pos", i))
+
+    # ------------------------------------------------------------------ iteration
+    def _take(self):
+        """(epoch, batchnum) of the batch being handed out; moves on to the next one."""
+        here = self._cursor.epoch, self._cursor.batchnum
+        self._cursor.step()
+        return here
+
     def get_next_batch(self):
-        if self.data_dic is None or len(self.batch_range) > 1:
+        if self.data_dic is None or len(self.batch_range) > 1:       # a one-batch range is read once
             self.data_dic = self.get_batch(self.curr_batchnum)
-        epoch, batchnum = self.curr_epoch, self.curr_batchnum
-        self.advance_batch()
-        return epoch, batchnum, self.data_dic
+        return self._take() + (self.data_dic,)
 
     def advance_batch(self):
-        self.batch_idx = self.get_next_batch_idx()
-        self.curr_batchnum = self.batch_range[self.batch_idx]
-        if self.batch_idx == 0:      # wrapped around: next epoch
-            self.curr_epoch += 1
+        self._cursor.step()
 
     def get_next_batch_idx(self):
-        return (self.batch_idx + 1) % len(self.batch_range)
+        return self._cursor.peek()
 
     def get_next_batch_num(self):
-        return self.batch_range[self.get_next_batch_idx()]
+        return self.batch_range[self._cursor.peek()]
 
-    # -- files -----------------------------------------------------------
+    # ------------------------------------------------------------------ files
     def get_data_file_name(self, batchnum=None):
-        if batchnum is None:
-            batchnum = self.curr_batchnum
-        return os.path.join(self.data_dir, "data_batch_%d" % batchnum)
+        return os.path.join(self.data_dir, "data_batch_%d" % (self.curr_batchnum if batchnum is None else batchnum))
 
     def get_batch(self, batch_num):
-        base = self.get_data_file_name(batch_num)
-        if not os.path.exists(base + ".1"):
-            return unpickle(base)
-        dic = unpickle(base + ".1")          # batch stored as sub-batches .1, .2, ...
-        idx = 2
-        while os.path.exists("%s.%d" % (base, idx)):
-            dic["data"] = n.r_[dic["data"], unpickle("%s.%d" % (base, idx))["data"]]
-            idx += 1
-        return dic
+        whole = self.get_data_file_name(batch_num)
+        pieces = []
+        while os.path.exists("%s.%d" % (whole, len(pieces) + 1)):
+            pieces.append(unpickle("%s.%d" % (whole, len(pieces) + 1)))
+        if not pieces:
+            return unpickle(whole)
+        batch = pieces[0]
+        if len(pieces) > 1:
+            batch["data"] = n.concatenate([p["data"] for p in pieces], axis=0)
+        return batch
 
     def get_data_dims(self, idx=0):
         return self.batch_meta["num_vis"]
@@ -82,7 +109,7 @@ class DataProvider(object):
 
     @staticmethod
     def get_batch_filenames(srcdir):
-        return sorted([f for f in os.listdir(srcdir) if DataProvider.BATCH_REGEX.match(f)], key=alphanum_key)
+        return sorted((f for f in os.listdir(srcdir) if DataProvider.BATCH_REGEX.match(f)), key=alphanum_key)
 
     @staticmethod
     def get_batch_nums(srcdir):
@@ -92,70 +119,22 @@ class DataProvider(object):
     def get_num_batches(srcdir):
         return len(DataProvider.get_batch_nums(srcdir))
 
-    # -- registry ----------------------------------------------------------
+    # ------------------------------------------------------------------ registry
     @classmethod
     def get_instance(cls, data_dir, batch_range=None, init_epoch=1, init_batchnum=None, type="default", dp_params=None, test=False):
-        type = type or DataProvider.get_batch_meta(data_dir)["dp_type"]     # the data may name its provider
-        if type.startswith("dummy-"):
-            name = "-".join(type.split("-")[:-1]) + "-n"
-            if name not in dp_types:
-                raise DataProviderException("No such data provider: %s" % type)
-            return dp_classes[name](int(type.split("-")[-1]))
-        if type in dp_types:
-            return dp_classes[type](data_dir, batch_range, init_epoch, init_batchnum, dp_params or {}, test)
-        raise DataProviderException("No such data provider: %s" % type)
+        kind = type or DataProvider.get_batch_meta(data_dir)["dp_type"]      # no --data-provider: the data names its own
+        head, _, tail = kind.rpartition("-")
+        if kind.startswith("dummy-") and head + "-n" in dp_classes and tail.isdigit():
+            return dp_classes[head + "-n"](int(tail))                        # "dummy-cn-3072": the dimensionality rides in the name
+        if kind not in dp_classes or kind.endswith("-n"):
+            raise DataProviderException("No such data provider: %s" % kind)
+        return dp_classes[kind](data_dir, batch_range, init_epoch, init_batchnum, {} if dp_params is None else dp_params, test)
 
     @classmethod
     def register_data_provider(cls, name, desc, _class):
-        if name in dp_types:
-            if dp_classes[name] is _class:
-                return
+        if dp_classes.get(name, _class) is not _class:
             raise DataProviderException("Data provider %s already registered" % name)
-        dp_types[name] = desc
-        dp_classes[name] = _class
-
-
-class DummyDataProvider(DataProvider):
-    def __init__(self, data_dim):
-        self.batch_range = [1]
-        self.batch_meta = {"num_vis": data_dim, "data_in_rows": True}
-        self.curr_epoch = 1
-        self.curr_batchnum = 1
-        self.batch_idx = 0
-
-    def get_next_batch(self):
-        self.advance_batch()
-        return self.curr_epoch, self.curr_batchnum, {"data": nr.rand(512, self.get_data_dims()).astype(n.single)}
-
-
-class LabeledDummyDataProvider(DummyDataProvider):
-    """512 uniform-random cases with uniform-random integer labels per batch (Python/data.py:217-239)."""
-
-    def __init__(self, data_dim, num_classes=10, num_cases=512):
-        DummyDataProvider.__init__(self, data_dim)
-        self.batch_meta["label_names"] = [str(x) for x in range(num_classes)]
-        self.num_cases = num_cases
-        self.num_classes = num_classes
-
-    def get_num_classes(self):
-        return self.num_classes
-
-    def get_next_batch(self):
-        self.advance_batch()
-        data = nr.rand(self.num_cases, self.get_data_dims()).astype(n.single)
-        labels = n.require(n.c_[nr.randint(0, self.num_classes, self.num_cases)], requirements="C", dtype=n.single)
-        return self.curr_epoch, self.curr_batchnum, {"data": data, "labels": labels}
-
-
-class MemoryDataProvider(DataProvider):
-    def __init__(self, data_dir, batch_range, init_epoch=1, init_batchnum=None, dp_params=None, test=False):
-        DataProvider.__init__(self, data_dir, batch_range, init_epoch, init_batchnum, dp_params, test)
-        self.data_dic = [self.get_batch(i) for i in self.batch_range]
-
-    def get_next_batch(self):
-        epoch, batchnum = self.curr_epoch, self.curr_batchnum
-        self.advance_batch()
-        return epoch, batchnum, self.data_dic[batchnum - self.batch_range[0]]
+        dp_types[name], dp_classes[name] = desc, _class
 
 
 class LabeledDataProvider(DataProvider):
@@ -163,30 +142,68 @@ class LabeledDataProvider(DataProvider):
         return len(self.batch_meta["label_names"])
 
 
-class LabeledMemoryDataProvider(LabeledDataProvider):
+class MemoryDataProvider(DataProvider):
+    """Every batch of the range is read at construction; get_next_batch only indexes."""
+
     def __init__(self, data_dir, batch_range, init_epoch=1, init_batchnum=None, dp_params=None, test=False):
-        LabeledDataProvider.__init__(self, data_dir, batch_range, init_epoch, init_batchnum, dp_params, test)
-        self.data_dic = []
-        for i in self.batch_range:
-            d = unpickle(self.get_data_file_name(i))
-            d["labels"] = n.c_[n.require(d["labels"], dtype=n.single)]
-            self.data_dic.append(d)
+        DataProvider.__init__(self, data_dir, batch_range, init_epoch, init_batchnum, dp_params, test)
+        self.data_dic = [self._resident(b) for b in self.batch_range]
+
+    def _resident(self, batchnum):
+        return self.get_batch(batchnum)
 
     def get_next_batch(self):
-        epoch, batchnum = self.curr_epoch, self.curr_batchnum
-        self.advance_batch()
-        return epoch, batchnum, self.data_dic[batchnum - self.batch_range[0]]
+        epoch, batchnum = self._take()
+        return epoch, batchnum, self.data_dic[self.batch_range.index(batchnum)]
 
 
-dp_types = {"default": "The default data provider; loads one batch into memory at a time",
-            "memory": "Loads the entire dataset into memory",
-            "labeled": "Returns data and labels (used by classifiers)",
-            "labeled-memory": "Combination labeled + memory",
-            "dummy-n": "Dummy data provider for n-dimensional data",
-            "dummy-labeled-n": "Labeled dummy data provider for n-dimensional data"}
-dp_classes = {"default": DataProvider,
-              "memory": MemoryDataProvider,
-              "labeled": LabeledDataProvider,
-              "labeled-memory": LabeledMemoryDataProvider,
-              "dummy-n": DummyDataProvider,
-              "dummy-labeled-n": LabeledDummyDataProvider}
+class LabeledMemoryDataProvider(MemoryDataProvider, LabeledDataProvider):
+    def _resident(self, batchnum):
+        batch = unpickle(self.get_data_file_name(batchnum))
+        batch["labels"] = n.asarray(batch["labels"], dtype=n.single).reshape(-1, 1)
+        return batch
+
+
+class DummyDataProvider(DataProvider):
+    """No files: uniform-random (512, dims) batches."""
+    num_cases = 512
+
+    def __init__(self, data_dim):
+        self._start([1])
+        self.batch_meta = {"num_vis": data_dim, "data_in_rows": True}
+
+    def _draw(self):
+        return {"data": nr.rand(self.num_cases, self.get_data_dims()).astype(n.single)}
+
+    def get_next_batch(self):
+        self.advance_batch()          # (the reference's dummies step first, so the first batch reports epoch 2)
+        return self.curr_epoch, self.curr_batchnum, self._draw()
+
+
+class LabeledDummyDataProvider(DummyDataProvider):
+    """... plus a (cases, 1) column of uniform-random integer labels."""
+
+    def __init__(self, data_dim, num_classes=10, num_cases=512):
+        DummyDataProvider.__init__(self, data_dim)
+        self.num_classes, self.num_cases = num_classes, num_cases
+        self.batch_meta["label_names"] = [str(c) for c in range(num_classes)]
+
+    def get_num_classes(self):
+        return self.num_classes
+
+    def _draw(self):
+        batch = DummyDataProvider._draw(self)
+        batch["labels"] = nr.randint(0, self.num_classes, self.num_cases).astype(n.single).reshape(-1, 1)
+        return batch
+
+
+PROVIDERS = [   # (name, class, description)
+    ("default", DataProvider, "The default data provider; loads one batch into memory at a time"),
+    ("memory", MemoryDataProvider, "Loads the entire dataset into memory"),
+    ("labeled", LabeledDataProvider, "Returns data and labels (used by classifiers)"),
+    ("labeled-memory", LabeledMemoryDataProvider, "Combination labeled + memory"),
+    ("dummy-n", DummyDataProvider, "Dummy data provider for n-dimensional data"),
+    ("dummy-labeled-n", LabeledDummyDataProvider, "Labeled dummy data provider for n-dimensional data"),
+]
+dp_types = dict((name, desc) for name, _, desc in PROVIDERS)
+dp_classes = dict((name, klass) for name, klass, _ in PROVIDERS)

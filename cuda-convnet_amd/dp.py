@@ -35,12 +35,30 @@ def connect(libmodel, rank, world, force_single=False):
 
 
 def shard_columns(cases, minibatch, rank, world):
-    """Column indices of rank `rank`: global minibatch i covers cases [i*mb*world, (i+1)*mb*world);
-    each rank takes an equal contiguous slice of it (a remainder that does not divide is dropped)."""
+    """Column indices of rank `rank`: global minibatch i covers cases [i*mb*world, (i+1)*mb*world) and every rank takes a
+    contiguous slice of it.  Full global minibatches split evenly; a ragged last one (the reference's tail minibatch,
+    Kernel/src/data/data.cu:67-104, e.g. 10 000 cases = 78 x 128 + 16) is dealt out as evenly as it goes -- the first
+    `tail % world` ranks take one case more -- so no case is dropped.  Gradients of that minibatch must then be scaled by
+    its true global size, not by local cases x world: pass global_cases(...) to libkernel.startBatch."""
     import numpy as n
     gmb = minibatch * world
     cols = []
     for s in range(0, cases, gmb):
-        per = (min(cases, s + gmb) - s) // world
-        cols.append(n.arange(s + rank * per, s + (rank + 1) * per))
+        t = min(cases, s + gmb) - s
+        if t < world:
+            # fewer cases than ranks: some rank would sit out the minibatch and its all-reduce would never complete.  The
+            # only case left out anywhere (at most world - 1 cases of a batch); said aloud, once per call, by rank 0.
+            if rank == 0:
+                print("dp.shard_columns: the last %d case(s) of this %d-case batch are fewer than the %d ranks and are skipped" % (t, cases, world))
+            break
+        per, extra = divmod(t, world)
+        lo = s + rank * per + min(rank, extra)
+        cols.append(n.arange(lo, lo + per + (1 if rank < extra else 0)))
     return n.concatenate(cols) if cols else n.zeros(0, dtype=n.int64)
+
+
+def global_cases(cases, minibatch, world):
+    """Cases of a `cases`-case batch that shard_columns hands out over all ranks (everything, unless the tail is shorter than
+    the world size): the third argument of libkernel.startBatch, from which it takes each minibatch's true global size."""
+    t = cases % (minibatch * world)
+    return cases - t if 0 < t < world else cases

@@ -1,18 +1,42 @@
-"""Training driver base class (Python 3): option handling, data-provider set-up, the
-train / test / checkpoint loop.  Behaviour follows the reference's Python/gpumodel.py:44-348:
-one batch is handed to the native module with `startBatch` while the next one is being loaded,
-`finishBatch` returns the cost, every `testing_freq` batches the weights are synced to the host,
-a test batch is evaluated and a checkpoint `<save_path>/<save_file>/<epoch>.<batch>` is written
-as a pickle of {"model_state", "op"}."""
+"""Model-independent half of the training driver (Python 3): options, data providers, the train / test / checkpoint cycle
+around a native module that exposes `startBatch` / `finishBatch` / `syncWithHost`.
+
+Contract kept from the reference's Python/gpumodel.py (its flags, stdout lines and checkpoint layout are the boundary users
+script against): option names and defaults; a checkpoint is `<save_path>/<save_file>/<epoch>.<batch>`, a pickle of
+{"model_state": ..., "op": ...}; `-f` resumes from the newest file of such a directory with the saved options as defaults;
+a test pass and a checkpoint every `testing_freq` batches; while the device works on batch i the host loads batch i+1.
+
+Subclasses (convnet.ConvNet) supply the hooks: import_model, init_model_state, init_model_lib, fill_excused_options,
+parse_batch_data, start_batch, the print_* family, conditional_save, aggregate_test_outputs."""
 import os
 import sys
-from os import linesep as NL
-from time import asctime, localtime, strftime, time
+import time
 
 from data import DataProvider, DataProviderException, dp_types
 from options import (BooleanOptionParser, FloatOptionParser, IntegerOptionParser, ListOptionParser, OptionException,
                      OptionExpression, OptionMissingException, OptionsParser, RangeOptionParser, StringOptionParser)
 from util import GPU_LOCK_NO_LOCK, UnpickleError, alphanum_key, get_gpu_lock, pickle, unpickle
+
+RULE = "========================="
+
+# (flag, attribute, parser, description, keyword arguments of add_option)
+BASE_OPTIONS = [
+    ("f", "load_file", StringOptionParser, "Load file", dict(default="", excuses=OptionsParser.EXCLUDE_ALL)),
+    ("train-range", "train_batch_range", RangeOptionParser, "Data batch range: training", {}),
+    ("test-range", "test_batch_range", RangeOptionParser, "Data batch range: testing", {}),
+    ("data-provider", "dp_type", StringOptionParser, "Data provider", dict(default="default")),
+    ("test-freq", "testing_freq", IntegerOptionParser, "Testing frequency", dict(default=25)),
+    ("epochs", "num_epochs", IntegerOptionParser, "Number of epochs", dict(default=500)),
+    ("data-path", "data_path", StringOptionParser, "Data path", {}),
+    ("save-path", "save_path", StringOptionParser, "Save path", {}),
+    ("max-filesize", "max_filesize_mb", IntegerOptionParser, "Maximum save file size (MB)", dict(default=5000)),
+    ("max-test-err", "max_test_err", FloatOptionParser, "Maximum test error for saving", {}),
+    ("num-gpus", "num_gpus", IntegerOptionParser, "Number of GPUs", dict(default=1)),
+    ("test-only", "test_only", BooleanOptionParser, "Test and quit?", dict(default=0)),
+    ("zip-save", "zip_save", BooleanOptionParser, "Compress checkpoints?", dict(default=0)),
+    ("test-one", "test_one", BooleanOptionParser, "Test on one batch at a time?", dict(default=1)),
+    ("gpu", "gpu", ListOptionParser(IntegerOptionParser), "GPU override", dict(default=OptionExpression("[-1] * num_gpus"))),
+]
 
 
 class ModelStateException(Exception):
@@ -21,50 +45,41 @@ class ModelStateException(Exception):
 
 class IGPUModel(object):
     def __init__(self, model_name, op, load_dic, filename_options=None, dp_params=None):
-        self.model_name = model_name
-        self.op = op
-        self.options = op.options
-        self.load_dic = load_dic
-        self.filename_options = filename_options
+        self.model_name, self.op, self.options = model_name, op, op.options
+        self.load_dic, self.filename_options = load_dic, filename_options
         self.dp_params = {} if dp_params is None else dp_params
+        self.range_train_outputs = []
         self.get_gpus()
         self.fill_excused_options()
-        self.range_train_outputs = []
-        for o in op.get_options_list():
-            setattr(self, o.name, o.value)
+        for opt in op.get_options_list():           # every option is an attribute of the model
+            setattr(self, opt.name, opt.value)
 
         if load_dic:
             self.model_state = load_dic["model_state"]
-            self.save_file = self.options["load_file"].value
-            if not os.path.isdir(self.save_file):
-                self.save_file = os.path.dirname(self.save_file)
+            given = self.options["load_file"].value
+            self.save_file = given if os.path.isdir(given) else os.path.dirname(given)
         else:
-            self.model_state = {}
+            self.model_state = {"train_outputs": [], "test_outputs": [], "epoch": 1, "batchnum": self.train_batch_range[0]}
             if filename_options is not None:
-                tags = ["%s_%s" % (char, self.options[opt].get_str_value()) for opt, char in filename_options]
-                self.save_file = model_name + "_" + "_".join(tags) + "_" + strftime("%Y-%m-%d_%H.%M.%S")
-            self.model_state["train_outputs"] = []
-            self.model_state["test_outputs"] = []
-            self.model_state["epoch"] = 1
-            self.model_state["batchnum"] = self.train_batch_range[0]
+                tags = ["%s_%s" % (char, self.options[name].get_str_value()) for name, char in filename_options]
+                self.save_file = "_".join([model_name] + tags + [time.strftime("%Y-%m-%d_%H.%M.%S")])
 
         self.init_data_providers()
         if load_dic:
-            self.train_data_provider.advance_batch()
+            self.train_data_provider.advance_batch()    # the checkpoint names the last batch that was trained on
         try:
             self.init_model_state()
         except ModelStateException as e:
             print(e)
             sys.exit(1)
-        for var, val in self.model_state.items():
-            setattr(self, var, val)
+        self.__dict__.update(self.model_state)      # epoch, batchnum, train_outputs, ... live on the model while it runs
         self.import_model()
         self.init_model_lib()
 
-    # -- hooks for subclasses ----------------------------------------------------------
+    # ---------------------------------------------------------------- hooks
     def import_model(self):
-        print("=========================")
-        print("Importing %s C++ module" % ("_" + self.model_name))
+        print(RULE)
+        print("Importing _%s C++ module" % self.model_name)
         self.libmodel = __import__("_" + self.model_name)
 
     def fill_excused_options(self):
@@ -84,59 +99,60 @@ class IGPUModel(object):
 
     def init_data_providers(self):
         self.dp_params["convnet"] = self
+        common = dict(type=self.dp_type, dp_params=self.dp_params)
         try:
-            self.test_data_provider = DataProvider.get_instance(self.data_path, self.test_batch_range, type=self.dp_type,
-                                                                dp_params=self.dp_params, test=True)
-            self.train_data_provider = DataProvider.get_instance(self.data_path, self.train_batch_range,
-                                                                 self.model_state["epoch"], self.model_state["batchnum"],
-                                                                 type=self.dp_type, dp_params=self.dp_params, test=False)
+            self.test_data_provider = DataProvider.get_instance(self.data_path, self.test_batch_range, test=True, **common)
+            self.train_data_provider = DataProvider.get_instance(self.data_path, self.train_batch_range, self.model_state["epoch"],
+                                                                 self.model_state["batchnum"], test=False, **common)
         except DataProviderException as e:
             print("Unable to create data provider: %s" % e)
             self.print_data_providers()
             sys.exit()
 
-    # -- main loop -----------------------------------------------------------------------
+    # ---------------------------------------------------------------- the cycle
     def start(self):
-        if self.test_only:
-            self.test_outputs += [self.get_test_error()]
-            self.print_test_results()
-            sys.exit(0)
-        self.train()
+        if not self.test_only:
+            return self.train()
+        self.test_outputs.append(self.get_test_error())
+        self.print_test_results()
+        sys.exit(0)
 
     def train(self):
-        print("=========================")
-        print("Training %s" % self.model_name)
+        for line in (RULE, "Training %s" % self.model_name):
+            print(line)
         self.op.print_values()
-        print("=========================")
+        print(RULE)
         self.print_model_state()
-        print("Running on device(s) %s" % ", ".join("%d" % d for d in self.device_ids))
-        print("Current time: %s" % asctime(localtime()))
+        print("Running on device(s) %s" % ", ".join(str(d) for d in self.device_ids))
+        print("Current time: %s" % time.asctime(time.localtime()))
         print("Saving checkpoints to %s" % os.path.join(self.save_path, self.save_file))
-        print("=========================")
-        next_data = self.get_next_batch()
+        print(RULE)
         self.range_train_outputs = []
+        upcoming = self.get_next_batch()
         while self.epoch <= self.num_epochs:
-            data = next_data
-            self.epoch, self.batchnum = data[0], data[1]
+            batch, began = upcoming, time.time()
+            self.epoch, self.batchnum = batch[0], batch[1]
             self.print_iteration()
             sys.stdout.flush()
-            t0 = time()
-            self.start_batch(data)
-            next_data = self.get_next_batch()       # overlaps host loading with the device work
-            batch_output = self.finish_batch()
-            self.train_outputs += [batch_output]
-            self.range_train_outputs += [batch_output]
+            self.start_batch(batch)
+            upcoming = self.get_next_batch()            # host I/O while the device trains
+            result = self.finish_batch()
+            self.train_outputs.append(result)
+            self.range_train_outputs.append(result)
             self.print_train_results()
             if self.get_num_batches_done() % self.testing_freq == 0:
-                self.sync_with_host()
-                self.test_outputs += [self.get_test_error()]
-                self.print_mean_train_results()
-                self.range_train_outputs = []
-                self.print_test_results()
-                self.print_test_status()
-                self.conditional_save()
-            self.print_train_time(time() - t0)
+                self.test_and_checkpoint()
+            self.print_train_time(time.time() - began)
         self.cleanup()
+
+    def test_and_checkpoint(self):
+        self.sync_with_host()
+        self.test_outputs.append(self.get_test_error())
+        self.print_mean_train_results()
+        self.range_train_outputs = []
+        self.print_test_results()
+        self.print_test_status()
+        self.conditional_save()
 
     def cleanup(self):
         sys.exit(0)
@@ -145,14 +161,16 @@ class IGPUModel(object):
         self.libmodel.syncWithHost()
 
     def get_num_batches_done(self):
-        return len(self.train_batch_range) * (self.epoch - 1) + self.batchnum - self.train_batch_range[0] + 1
+        per_epoch, first = len(self.train_batch_range), self.train_batch_range[0]
+        return per_epoch * (self.epoch - 1) + (self.batchnum - first) + 1
 
     def get_next_batch(self, train=True):
-        dp = self.train_data_provider if train else self.test_data_provider
-        return self.parse_batch_data(dp.get_next_batch(), train=train)
+        provider = self.train_data_provider if train else self.test_data_provider
+        return self.parse_batch_data(provider.get_next_batch(), train=train)
 
     def parse_batch_data(self, batch_data, train=True):
-        return batch_data[0], batch_data[1], batch_data[2]["data"]
+        epoch, batchnum, payload = batch_data
+        return epoch, batchnum, payload["data"]
 
     def start_batch(self, batch_data, train=True):
         self.libmodel.startBatch(batch_data[2], not train)
@@ -160,7 +178,26 @@ class IGPUModel(object):
     def finish_batch(self):
         return self.libmodel.finishBatch()
 
-    # -- reporting -----------------------------------------------------------------------
+    def get_test_error(self):
+        """One test batch (`test_one`) or the whole test range, loading the next batch while the device evaluates this one."""
+        results, last = [], self.test_batch_range[-1]
+        batch = self.get_next_batch(train=False)
+        while batch is not None:
+            self.start_batch(batch, train=False)
+            more = not self.test_one and batch[1] < last
+            upcoming = self.get_next_batch(train=False) if more else None
+            results.append(self.finish_batch())
+            if self.test_only:
+                print("batch %d: %s" % (batch[1], str(results[-1])))
+            sys.stdout.flush()
+            batch = upcoming
+        return self.aggregate_test_outputs(results)
+
+    def aggregate_test_outputs(self, test_outputs):
+        batches = 1 if self.test_one else len(self.test_batch_range)
+        return tuple(sum(column) / batches for column in zip(*test_outputs))
+
+    # ---------------------------------------------------------------- reporting
     def print_iteration(self):
         print("\t%d.%d..." % (self.epoch, self.batchnum), end=" ")
 
@@ -168,11 +205,11 @@ class IGPUModel(object):
         print("(%.3f sec)" % compute_time_py)
 
     def print_train_results(self):
-        batch_error = self.train_outputs[-1][0]
-        if not (batch_error > 0 and batch_error < 2e20):
-            print("Crazy train error: %.6f" % batch_error)
+        cost = self.train_outputs[-1][0]
+        if not 0 < cost < 2e20:
+            print("Crazy train error: %.6f" % cost)
             self.cleanup()
-        print("Train error: %.6f " % batch_error, end=" ")
+        print("Train error: %.6f " % cost, end=" ")
 
     def print_mean_train_results(self):
         print("\n======================Train output======================")
@@ -180,44 +217,22 @@ class IGPUModel(object):
         self.print_mean_cost(self.range_train_outputs)
 
     def print_test_results(self):
-        print("%s\t\tTest error: %.6f" % (NL, self.test_outputs[-1][0]), end=" ")
+        print("%s\t\tTest error: %.6f" % (os.linesep, self.test_outputs[-1][0]), end=" ")
 
     def print_test_status(self):
-        better = len(self.test_outputs) == 1 or self.test_outputs[-1][0] < self.test_outputs[-2][0]
-        print("ok" if better else "WORSE", end=" ")
+        errs = [t[0] for t in self.test_outputs[-2:]]
+        print("ok" if len(errs) == 1 or errs[1] < errs[0] else "WORSE", end=" ")
 
     def conditional_save(self):
-        batch_error = self.test_outputs[-1][0]
-        if batch_error > 0 and batch_error < self.max_test_err:
+        if 0 < self.test_outputs[-1][0] < self.max_test_err:
             self.save_state()
         else:
             print("\tTest error > %g, not saving." % self.max_test_err, end=" ")
 
-    def aggregate_test_outputs(self, test_outputs):
-        div = 1 if self.test_one else len(self.test_batch_range)
-        return tuple(sum(t[r] for t in test_outputs) / div for r in range(len(test_outputs[-1])))
-
-    def get_test_error(self):
-        next_data = self.get_next_batch(train=False)
-        test_outputs = []
-        while True:
-            data = next_data
-            self.start_batch(data, train=False)
-            load_next = not self.test_one and data[1] < self.test_batch_range[-1]
-            if load_next:
-                next_data = self.get_next_batch(train=False)
-            test_outputs += [self.finish_batch()]
-            if self.test_only:
-                print("batch %d: %s" % (data[1], str(test_outputs[-1])))
-            if not load_next:
-                break
-            sys.stdout.flush()
-        return self.aggregate_test_outputs(test_outputs)
-
-    # -- state ---------------------------------------------------------------------------
+    # ---------------------------------------------------------------- state
     def set_var(self, var_name, var_val):
-        setattr(self, var_name, var_val)
         self.model_state[var_name] = var_val
+        setattr(self, var_name, var_val)
         return var_val
 
     def get_var(self, var_name):
@@ -227,47 +242,33 @@ class IGPUModel(object):
         return var_name in self.model_state
 
     def save_state(self):
-        for att in self.model_state:
-            if hasattr(self, att):
-                self.model_state[att] = getattr(self, att)
-        dic = {"model_state": self.model_state, "op": self.op}
-        checkpoint_dir = os.path.join(self.save_path, self.save_file)
-        if not os.path.exists(checkpoint_dir):
-            os.makedirs(checkpoint_dir)
-        pickle(os.path.join(checkpoint_dir, "%d.%d" % (self.epoch, self.batchnum)), dic, compress=self.zip_save)
+        for key in self.model_state:                # pull the running values back into the state dict
+            if hasattr(self, key):
+                self.model_state[key] = getattr(self, key)
+        where = os.path.join(self.save_path, self.save_file)
+        os.makedirs(where, exist_ok=True)
+        pickle(os.path.join(where, "%d.%d" % (self.epoch, self.batchnum)), {"model_state": self.model_state, "op": self.op}, compress=self.zip_save)
 
     @staticmethod
     def load_checkpoint(load_dir):
-        if os.path.isdir(load_dir):
-            return unpickle(os.path.join(load_dir, sorted(os.listdir(load_dir), key=alphanum_key)[-1]))
-        return unpickle(load_dir)
+        if not os.path.isdir(load_dir):
+            return unpickle(load_dir)
+        newest = max(os.listdir(load_dir), key=alphanum_key)
+        return unpickle(os.path.join(load_dir, newest))
 
-    # -- options ---------------------------------------------------------------------------
+    # ---------------------------------------------------------------- options
     @staticmethod
     def get_options_parser():
         op = OptionsParser()
-        op.add_option("f", "load_file", StringOptionParser, "Load file", default="", excuses=OptionsParser.EXCLUDE_ALL)
-        op.add_option("train-range", "train_batch_range", RangeOptionParser, "Data batch range: training")
-        op.add_option("test-range", "test_batch_range", RangeOptionParser, "Data batch range: testing")
-        op.add_option("data-provider", "dp_type", StringOptionParser, "Data provider", default="default")
-        op.add_option("test-freq", "testing_freq", IntegerOptionParser, "Testing frequency", default=25)
-        op.add_option("epochs", "num_epochs", IntegerOptionParser, "Number of epochs", default=500)
-        op.add_option("data-path", "data_path", StringOptionParser, "Data path")
-        op.add_option("save-path", "save_path", StringOptionParser, "Save path")
-        op.add_option("max-filesize", "max_filesize_mb", IntegerOptionParser, "Maximum save file size (MB)", default=5000)
-        op.add_option("max-test-err", "max_test_err", FloatOptionParser, "Maximum test error for saving")
-        op.add_option("num-gpus", "num_gpus", IntegerOptionParser, "Number of GPUs", default=1)
-        op.add_option("test-only", "test_only", BooleanOptionParser, "Test and quit?", default=0)
-        op.add_option("zip-save", "zip_save", BooleanOptionParser, "Compress checkpoints?", default=0)
-        op.add_option("test-one", "test_one", BooleanOptionParser, "Test on one batch at a time?", default=1)
-        op.add_option("gpu", "gpu", ListOptionParser(IntegerOptionParser), "GPU override", default=OptionExpression("[-1] * num_gpus"))
+        for flag, attr, parser, desc, kw in BASE_OPTIONS:
+            op.add_option(flag, attr, parser, desc, **kw)
         return op
 
     @staticmethod
     def print_data_providers():
         print("Available data providers:")
-        for dp, desc in dp_types.items():
-            print("    %s: %s" % (dp, desc))
+        for name in dp_types:
+            print("    %s: %s" % (name, dp_types[name]))
 
     def get_gpus(self):
         self.device_ids = [get_gpu_lock(g) for g in self.op.get_value("gpu")]
@@ -277,14 +278,14 @@ class IGPUModel(object):
 
     @staticmethod
     def parse_options(op, argv=None):
+        """(options, checkpoint or None); with -f the checkpoint's options are the defaults and the command line overrides."""
         try:
             load_dic = None
-            options = op.parse(argv=argv)
-            if options["load_file"].value_given:
-                load_dic = IGPUModel.load_checkpoint(options["load_file"].value)
-                old_op = load_dic["op"]
-                old_op.merge_from(op)
-                op = old_op
+            given = op.parse(argv=argv)
+            if given["load_file"].value_given:
+                load_dic = IGPUModel.load_checkpoint(given["load_file"].value)
+                load_dic["op"].merge_from(op)
+                op = load_dic["op"]
             op.eval_expr_defaults()
             return op, load_dic
         except OptionMissingException as e:

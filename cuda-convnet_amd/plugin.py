@@ -1,46 +1,38 @@
-"""Python half of the plugin mechanism: parsers for the layer / neuron types that live in
-Plugins/*.so (Python/plugin.py:18-62 of the reference): the NIN `cccp` cross-channel layer, the
-`dropout[prob]` neuron and the `cost.gsinlabel` cost.  `layer.py` merges these two registries
-into its own at import time."""
-from layer import CostParser, LayerParsingError, ParamNeuronParser, WeightLayerParser
-
-
-class GroupSparsityInLabelCostParser(CostParser):
-    def __init__(self):
-        CostParser.__init__(self, num_inputs=2)
-
-    def parse(self, name, mcp, prev_layers, model=None):
-        dic = CostParser.parse(self, name, mcp, prev_layers, model)
-        if dic["numInputs"][0] != 1:
-            raise LayerParsingError("Layer '%s': dimensionality of first input must be 1" % name)
-        dic["channels"] = mcp.safe_get_int(name, "channels")
-        dic["imgSize"] = mcp.safe_get_int(name, "imgSize")
-        print("Initialized groupSparsityInLabel cost '%s' with %d channels and %dx%d inputs" % (name, dic["channels"], dic["imgSize"], dic["imgSize"]))
-        return dic
+"""Config-side half of the plugin mechanism: the schemas of the layer / neuron types whose device code lives in
+Plugins/*.so (the reference's Python/plugin.py declares the same three): NIN's `cccp` cross-channel layer, the `dropout[prob]`
+neuron and the `cost.gsinlabel` cost.  layer.py folds `extra_layer_parsers` / `extra_neuron_parsers` into its registries at
+import; a third-party plugin adds its own types with `LayerParser.register_layer_parser`."""
+from layer import CostParser, Key, LayerParsingError, NeuronParser, WeightLayerParser
 
 
 class CCCPLayerParser(WeightLayerParser):
-    """Cascaded cross-channel parametric pooling = a 1x1 convolution over `in_nodes` input maps
-    producing `out_nodes` maps (per `channels` slice).  Weights (in_nodes, out_nodes*channels)
-    Fortran-ordered, bias (1, out_nodes*channels)."""
+    """Cascaded cross-channel parametric pooling: at every pixel, `in_nodes` input maps -> `out_nodes` output maps through one
+    shared matrix (a 1x1 convolution), independently in each of `channels` slices.  Weights (in_nodes, out_nodes*channels)
+    Fortran-ordered, biases (1, out_nodes*channels)."""
+    flags = dict(gradConsumer=True, usesActs=False)
+    keys = WeightLayerParser.keys + (Key("channels", "int"), Key("in_nodes", "int"), Key("out_nodes", "int"))
 
-    def parse(self, name, mcp, prev_layers, model=None):
-        dic = WeightLayerParser.parse(self, name, mcp, prev_layers, model)
-        dic["usesActs"] = False
-        dic["channels"] = mcp.safe_get_int(name, "channels")
-        dic["in_nodes"] = mcp.safe_get_int(name, "in_nodes")
-        dic["out_nodes"] = mcp.safe_get_int(name, "out_nodes")
-        pixels = dic["numInputs"][0] // (dic["in_nodes"] * dic["channels"])
-        dic["outputs"] = dic["out_nodes"] * dic["channels"] * pixels
+    def build(self, mcp):
+        dic = self.dic
+        maps_out = dic["out_nodes"] * dic["channels"]
+        dic["outputs"] = maps_out * (dic["numInputs"][0] // (dic["in_nodes"] * dic["channels"]))
         self.verify_num_range(dic["outputs"], "outputs", 1, None)
-        self.make_weights(dic["initW"], [dic["in_nodes"]], [dic["out_nodes"] * dic["channels"]], order="F")
-        self.make_biases(1, dic["out_nodes"] * dic["channels"], order="F")
-        print("Initialized filter-fully-connected layer '%s', producing %d outputs in %d channels" % (name, dic["out_nodes"], dic["channels"]))
-        return dic
+        self.make_weights(dic["initW"], [dic["in_nodes"]], [maps_out], order="F")
+        self.make_biases(1, maps_out, order="F")
+        print("Initialized filter-fully-connected layer '%s', producing %d outputs in %d channels" % (dic["name"], dic["out_nodes"], dic["channels"]))
 
 
-extra_layer_parsers = {"cost.gsinlabel": lambda: GroupSparsityInLabelCostParser(),
-                       "cccp": lambda: CCCPLayerParser()}
+class GroupSparsityInLabelCostParser(CostParser):
+    """Inputs: labels, then (channels, imgSize, imgSize) maps whose per-class groups the cost keeps sparse."""
+    num_inputs = 2
+    keys = (Key("channels", "int"), Key("imgSize", "int"))
 
-extra_neuron_parsers = sorted([ParamNeuronParser("dropout[prob]", "f(x) = rand() < prob ? 0:x", uses_acts=False, uses_inputs=False)],
-                              key=lambda x: x.type)
+    def build(self, mcp):
+        dic = self.dic
+        if dic["numInputs"][0] != 1:
+            raise LayerParsingError("Layer '%s': dimensionality of first input must be 1" % dic["name"])
+        print("Initialized groupSparsityInLabel cost '%s' with %d channels and %dx%d inputs" % (dic["name"], dic["channels"], dic["imgSize"], dic["imgSize"]))
+
+
+extra_layer_parsers = {"cccp": CCCPLayerParser, "cost.gsinlabel": GroupSparsityInLabelCostParser}
+extra_neuron_parsers = [NeuronParser("dropout[prob]", "f(x) = rand() < prob ? 0:x", uses_acts=False, uses_inputs=False)]

@@ -157,7 +157,7 @@ class GoldenNet(object):
         """Fills self.grads (activity gradients) and self.wgrads / self.bgrads (already scaled by
         eps / numCases as the reference does, layer.cu:491-523; scale 1 under PASS_GC)."""
         L, A, N = self.layers, self.acts, self.N
-        Ng = N * self.world
+        Ng = self.global_cases if getattr(self, 'global_cases', 0) else N * self.world   # data parallel: cases of the GLOBAL minibatch
         g = {}
         self.wgrads, self.bgrads = {}, {}
 

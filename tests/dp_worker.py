@@ -32,13 +32,15 @@ def main():
     assert lib.joined == (rank, world, bytes(range(128)))
     dist = dp.init_control_group()
 
-    mini, cases = 8, 40          # global minibatch 16: two full ones + a tail of 8 (4 per rank)
+    mini, cases = 8, 43          # global minibatch 16: two full ones + a ragged tail of 11 (6 + 5)
     layers, dims, classes = modelutil.load_net("gc-small", seed=11)
     data = modelutil.synthetic_batch(dims, classes, cases)
     cols = dp.shard_columns(cases, mini, rank, world)
     mine = [d[:, cols] for d in data]
     net = GoldenNet(layers, world=world)
-    for s in range(0, mine[0].shape[1], mini):
+    total = dp.global_cases(cases, mini, world)
+    for i, s in enumerate(range(0, mine[0].shape[1], mini)):
+        net.global_cases = min(mini * world, total - i * mini * world)     # what libkernel derives from startBatch's third argument
         net.fprop([d[:, s:s + mini] for d in mine])
         net.bprop()
         for store in (net.wgrads, net.bgrads):
