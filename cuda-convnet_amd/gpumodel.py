@@ -62,7 +62,8 @@ class IGPUModel(object):
             self.model_state = {"train_outputs": [], "test_outputs": [], "epoch": 1, "batchnum": self.train_batch_range[0]}
             if filename_options is not None:
                 tags = ["%s_%s" % (char, self.options[name].get_str_value()) for name, char in filename_options]
-                self.save_file = "_".join([model_name] + tags + [time.strftime("%Y-%m-%d_%H.%M.%S")])
+                # "<model>_<c_value>_..._<time>"; with no tags the two separators stay ("ConvNet__<time>"), as tools expect
+                self.save_file = "%s_%s_%s" % (model_name, "_".join(tags), time.strftime("%Y-%m-%d_%H.%M.%S"))
 
         self.init_data_providers()
         if load_dic:
