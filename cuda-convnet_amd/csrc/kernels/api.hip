@@ -38,14 +38,19 @@ int conv_img_acts_impl(const float*, const float*, float*, int, int, int, int, i
                        float, float*, int, hipStream_t);
 int conv_split_plan(int, long, int, int, int*);
 int conv_weight_acts_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int, int, int, int,
-                          float, float, hipStream_t);
+                          float, float, float*, long, float, hipStream_t);
 int conv_weight_grad_plan(int, int, int, int, int, int, int*);
 void set_tune_inhibit(bool);
 void set_describe(char*, int);
 bool describing();
 int gemm_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, float, float, const float*, int,
-              const float*, int, int, long, unsigned*, const unsigned*, hipStream_t);
+              const float*, int, int, long, unsigned*, const unsigned*, float*, long, float, hipStream_t);
 
+}  // namespace mc
+// (elementwise.hip) two column sums over the same number of rows in one launch; internal, not part of the C-ABI contract
+extern "C" int mc__sum_cols_pair(const float* v1, float* out1, int cols1, float sT1, float sO1, const float* v2, float* out2, int cols2,
+                                 float sO2, int rows, int tallMin, hipStream_t st);
+namespace mc {
 namespace {
 
 constexpr int TPB = 256;
@@ -400,7 +405,7 @@ int mc_conv_weight_acts(const float* images, const float* hidActs, float* target
     MC_REQUIRE(images && hidActs && targets, "mc_conv_weight_acts: null pointer");
     return conv_weight_acts_impl(images, hidActs, targets, numImages, numImgColors, imgSizeY, imgSizeX, numFilters,
                                  filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups, partialSum, 0,
-                                 scaleTargets, scaleOutput, S(s));
+                                 scaleTargets, scaleOutput, nullptr, 0, 0.f, S(s));
 }
 
 int mc_local_weight_acts(const float* images, const float* hidActs, float* targets, int numImages, int numImgColors,
@@ -412,7 +417,7 @@ int mc_local_weight_acts(const float* images, const float* hidActs, float* targe
     // module's chunk IS that module's filter bank.
     return conv_weight_acts_impl(images, hidActs, targets, numImages, numImgColors, imgSizeY, imgSizeX, numFilters,
                                  filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 1, 0,
-                                 scaleTargets, scaleOutput, S(s));
+                                 scaleTargets, scaleOutput, nullptr, 0, 0.f, S(s));
 }
 
 int mc_conv_weight_acts_pick_partial_sum(int numImages, int numImgColors, int numFilters, int filterSize, int numModules,
@@ -462,7 +467,7 @@ size_t mc_gemm_workspace_bytes(int m, int n, int k) {
 static int gemm_entry(const char* who, const float* A, const float* B, float* C, int m, int n, int k, int transA, int transB, int lda,
                       int ldb, int ldc, float scaleTargets, float scaleOutput, const float* rowBias, int neuron, const float* mask,
                       int ldmask, void* workspace, size_t workspaceBytes, mcStream_t s, unsigned* bitsOut = nullptr,
-                      const unsigned* bitsIn = nullptr) {
+                      const unsigned* bitsIn = nullptr, float* rowSums = nullptr, float sumScale = 0.f) {
     MC_REQUIRE(A && B && C, "%s: null pointer", who);
     MC_REQUIRE(m > 0 && n > 0 && k > 0, "%s: non-positive dimension (%d,%d,%d)", who, m, n, k);
     MC_REQUIRE(lda >= (transA ? m : k) && ldb >= (transB ? k : n) && ldc >= n, "%s: leading dimension too small", who);
@@ -472,14 +477,20 @@ static int gemm_entry(const char* who, const float* A, const float* B, float* C,
                    (size_t)m * ldc < (1ull << 30) && (!mask || (size_t)m * ldmask < (1ull << 30)),
                "%s: operand exceeds the 4 GiB buffer-descriptor range", who);
     int chunks = (bitsOut || bitsIn) ? 1 : pick_gemm_chunks(m, n, k);   // the bit-mask epilogues live in the unsplit product
-    if (chunks > 1 && workspace && workspaceBytes >= (size_t)chunks * m * n * sizeof(float) && aligned16(workspace)) {
+    // with row sums the chunks' m partial sums each follow the slabs
+    const size_t slabBytes = (size_t)chunks * ((size_t)m * n + (rowSums ? (size_t)m : 0)) * sizeof(float);
+    if (chunks > 1 && workspace && workspaceBytes >= slabBytes && aligned16(workspace)) {
         float* slabs = static_cast<float*>(workspace);
+        float* sumSlabs = slabs + (size_t)chunks * m * n;
+        const long sumStride = m;
         int rc = gemm_impl(A, B, slabs, m, n, k, transA, transB, lda, ldb, n, 0.f, 1.f, nullptr, MC_NEURON_NONE, nullptr, 0, chunks,
-                           (long)m * n, nullptr, nullptr, S(s));
+                           (long)m * n, nullptr, nullptr, rowSums ? sumSlabs : nullptr, sumStride, 1.f, S(s));
         if (rc) return rc;
         // gemm_impl may round the chunk size up; recompute how many slabs were written
         int kChunk = (ceil_div(k, chunks) + 31) / 32 * 32;
         const int written = ceil_div(k, kChunk);
+        if (rowSums && ldc == n && !rowBias && neuron == MC_NEURON_NONE && !mask)   // plain contiguous C: slabs and row sums in one launch
+            return mc__sum_cols_pair(slabs, C, m * n, scaleTargets, scaleOutput, sumSlabs, rowSums, m, sumScale, written, 16, S(s));
         if (n % 4 == 0 && ldc % 4 == 0 && aligned16(C) && written >= 16)
             hipLaunchKernelGGL(k_splitk_reduce_tall, dim3(ceil_div((long)m * (n / 4), 16)), dim3(256), 0, S(s),
                                reinterpret_cast<const float4*>(slabs), C, m, n / 4, ldc, written, scaleOutput, scaleTargets, rowBias, neuron,
@@ -487,10 +498,26 @@ static int gemm_entry(const char* who, const float* A, const float* B, float* C,
         else
             hipLaunchKernelGGL(k_splitk_reduce, dim3(grid_items((size_t)m * n)), dim3(TPB), 0, S(s), slabs, C, m, n, ldc,
                                written, scaleOutput, scaleTargets, rowBias, neuron, mask, ldmask);
+        if (launch_status("mc_gemm(split-k reduce)") != MC_OK) return MC_ELAUNCH;
+        if (rowSums)   // the chunks' partial row sums: a (written x m) matrix summed over its rows (parallel over the chunks too)
+            return mc_sum_cols(sumSlabs, rowSums, written, m, 0.f, sumScale, s);
         return launch_status("mc_gemm(split-k reduce)");
     }
     return gemm_impl(A, B, C, m, n, k, transA, transB, lda, ldb, ldc, scaleTargets, scaleOutput, rowBias, neuron, mask, ldmask, 1, 0,
-                     bitsOut, bitsIn, S(s));
+                     bitsOut, bitsIn, rowSums, 0, sumScale, S(s));
+}
+
+size_t mc_gemm_row_sums_workspace_bytes(int m, int n, int k) {
+    if (m <= 0 || n <= 0 || k <= 0) return 0;
+    const int chunks = pick_gemm_chunks(m, n, k);
+    return chunks > 1 ? (size_t)chunks * ((size_t)m * n + m) * sizeof(float) : 0;
+}
+
+int mc_gemm_row_sums(const float* A, const float* B, float* C, int m, int n, int k, int lda, int ldb, int ldc, float scaleTargets,
+                     float scaleOutput, float* rowSums, float sumScale, void* workspace, size_t workspaceBytes, mcStream_t s) {
+    MC_REQUIRE(rowSums, "mc_gemm_row_sums: null rowSums");
+    return gemm_entry("mc_gemm_row_sums", A, B, C, m, n, k, 0, 1, lda, ldb, ldc, scaleTargets, scaleOutput, nullptr, MC_NEURON_NONE, nullptr, 0,
+                      workspace, workspaceBytes, s, nullptr, nullptr, rowSums, sumScale);
 }
 
 int mc_gemm(const float* A, const float* B, float* C, int m, int n, int k, int transA, int transB, int lda, int ldb,
@@ -556,29 +583,59 @@ size_t mc_conv_weight_grad_workspace_bytes(int numImages, int numImgColors, int 
     return chunks > 1 ? (size_t)chunks * (numImgColors / numGroups) * filterSize * filterSize * numFilters * sizeof(float) : 0;
 }
 
-int mc_conv_weight_grad(const float* images, const float* hidActs, float* weightGrad, int numImages, int numImgColors,
-                        int imgSizeY, int imgSizeX, int numFilters, int filterSize, int paddingStart, int moduleStride,
-                        int numModulesY, int numModulesX, int numGroups, float scaleTargets, float scaleOutput,
-                        void* workspace, size_t workspaceBytes, mcStream_t s) {
-    MC_REQUIRE(images && hidActs && weightGrad, "mc_conv_weight_grad: null pointer");
+size_t mc_conv_weight_grad_bias_workspace_bytes(int numImages, int numImgColors, int numFilters, int filterSize, int numModules,
+                                                int numGroups) {
+    const size_t w = mc_conv_weight_grad_workspace_bytes(numImages, numImgColors, numFilters, filterSize, numModules, numGroups);
+    if (w == 0) return 0;
+    const size_t wel = (size_t)(numImgColors / numGroups) * filterSize * filterSize * numFilters;
+    return w + w / (wel * sizeof(float)) * numFilters * sizeof(float);   // every chunk: its slab and numFilters partial sums
+}
+
+static int conv_weight_grad_entry(const char* who, const float* images, const float* hidActs, float* weightGrad, float* biasGrad, int numImages,
+                                  int numImgColors, int imgSizeY, int imgSizeX, int numFilters, int filterSize, int paddingStart,
+                                  int moduleStride, int numModulesY, int numModulesX, int numGroups, float scaleTargets, float scaleOutput,
+                                  float biasScale, void* workspace, size_t workspaceBytes, mcStream_t s) {
+    MC_REQUIRE(images && hidActs && weightGrad, "%s: null pointer", who);
     MC_REQUIRE(numImages > 0 && numImgColors > 0 && numFilters > 0 && filterSize > 0 && numModulesY > 0 && numModulesX > 0 &&
                    numGroups > 0 && numImgColors % numGroups == 0 && numFilters % numGroups == 0,
-               "mc_conv_weight_grad: bad dimensions");
+               "%s: bad dimensions", who);
     const int M = numModulesY * numModulesX;
     int kc = 0;
     const int chunks = conv_weight_grad_plan(numImages, numImgColors, numFilters, filterSize, M, numGroups, &kc);
     if (chunks <= 1)
         return conv_weight_acts_impl(images, hidActs, weightGrad, numImages, numImgColors, imgSizeY, imgSizeX, numFilters, filterSize,
                                      paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 0, 0, scaleTargets, scaleOutput,
-                                     S(s));
+                                     biasGrad, 0, biasScale, S(s));
     const size_t wel = (size_t)(numImgColors / numGroups) * filterSize * filterSize * numFilters;
-    MC_REQUIRE(workspace && aligned16(workspace) && workspaceBytes >= (size_t)chunks * wel * sizeof(float),
-               "mc_conv_weight_grad: workspace of %zu bytes needed (mc_conv_weight_grad_workspace_bytes)", (size_t)chunks * wel * sizeof(float));
+    const size_t need = (size_t)chunks * (wel + (biasGrad ? numFilters : 0)) * sizeof(float);
+    MC_REQUIRE(workspace && aligned16(workspace) && workspaceBytes >= need, "%s: workspace of %zu bytes needed (%s_workspace_bytes)", who, need, who);
     float* slabs = static_cast<float*>(workspace);
+    float* sumSlabs = slabs + (size_t)chunks * wel;   // (chunks x numFilters), after the weight slabs
     int rc = conv_weight_acts_impl(images, hidActs, slabs, numImages, numImgColors, imgSizeY, imgSizeX, numFilters, filterSize,
-                                   paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 0, kc, 0.f, 1.f, S(s));
+                                   paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 0, kc, 0.f, 1.f,
+                                   biasGrad ? sumSlabs : nullptr, numFilters, 1.f, S(s));
     if (rc) return rc;
-    return mc_sum_cols(slabs, weightGrad, chunks, (int)wel, scaleTargets, scaleOutput, s);
+    if (!biasGrad) return mc_sum_cols(slabs, weightGrad, chunks, (int)wel, scaleTargets, scaleOutput, s);
+    return mc__sum_cols_pair(slabs, weightGrad, (int)wel, scaleTargets, scaleOutput, sumSlabs, biasGrad, numFilters, biasScale, chunks, 32, S(s));
+}
+
+int mc_conv_weight_grad(const float* images, const float* hidActs, float* weightGrad, int numImages, int numImgColors,
+                        int imgSizeY, int imgSizeX, int numFilters, int filterSize, int paddingStart, int moduleStride,
+                        int numModulesY, int numModulesX, int numGroups, float scaleTargets, float scaleOutput,
+                        void* workspace, size_t workspaceBytes, mcStream_t s) {
+    return conv_weight_grad_entry("mc_conv_weight_grad", images, hidActs, weightGrad, nullptr, numImages, numImgColors, imgSizeY, imgSizeX,
+                                  numFilters, filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups, scaleTargets,
+                                  scaleOutput, 0.f, workspace, workspaceBytes, s);
+}
+
+int mc_conv_weight_grad_bias(const float* images, const float* hidActs, float* weightGrad, float* biasGrad, int numImages,
+                             int numImgColors, int imgSizeY, int imgSizeX, int numFilters, int filterSize, int paddingStart,
+                             int moduleStride, int numModulesY, int numModulesX, int numGroups, float scaleTargets, float scaleOutput,
+                             float biasScale, void* workspace, size_t workspaceBytes, mcStream_t s) {
+    MC_REQUIRE(biasGrad, "mc_conv_weight_grad_bias: null biasGrad");
+    return conv_weight_grad_entry("mc_conv_weight_grad_bias", images, hidActs, weightGrad, biasGrad, numImages, numImgColors, imgSizeY,
+                                  imgSizeX, numFilters, filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups,
+                                  scaleTargets, scaleOutput, biasScale, workspace, workspaceBytes, s);
 }
 
 

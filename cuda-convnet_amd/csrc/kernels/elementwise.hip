@@ -257,9 +257,23 @@ __global__ void k_sum_cols(const float* __restrict__ v, float* out, int rows, in
         out[c] = (sT == 0.f ? 0.f : sT * out[c]) + sO * acc;
     }
 }
-__global__ void k_sum_cols4(const float4* __restrict__ v, float4* out, int rows, int cols4, float sT, float sO) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < (size_t)cols4; c += stride) {
+// A second, independent sum (same rows, overwriting) can ride in the same launch: blocks [nb1, gridDim.x) serve it.  The
+// split-K weight gradients reduce their slabs and the bias gradient's partial sums with one launch this way.
+struct SumSeg2 {
+    const float4* v;
+    float4* out;
+    int cols4;
+    float sO;
+    int nb1;   // blocks of the first sum; 0 = no second sum
+};
+__global__ void k_sum_cols4(const float4* __restrict__ v, float4* out, int rows, int cols4, float sT, float sO, SumSeg2 two) {
+    int blk = blockIdx.x, nblk = two.nb1 ? two.nb1 : gridDim.x;
+    if (two.nb1 && blk >= two.nb1) {
+        v = two.v; out = two.out; cols4 = two.cols4; sT = 0.f; sO = two.sO;
+        blk -= two.nb1; nblk = gridDim.x - two.nb1;
+    }
+    const size_t stride = (size_t)nblk * blockDim.x;
+    for (size_t c = (size_t)blk * blockDim.x + threadIdx.x; c < (size_t)cols4; c += stride) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int r = 0; r < rows; ++r) {
             const float4 x = v[(size_t)r * cols4 + c];
@@ -551,10 +565,16 @@ int mc_sum_rows(const float* v, float* out, int rows, int cols, float sT, float 
 
 // rows >> 1: workgroup = 16 float4 columns x 16 row groups; each thread adds rows rg, rg+16, ...
 // in order, then the 16 partials of a column are added in a fixed tree -> run-to-run deterministic.
-__global__ void __launch_bounds__(256) k_sum_cols4_tall(const float4* __restrict__ v, float4* out, int rows, int cols4, float sT, float sO) {
+__global__ void __launch_bounds__(256) k_sum_cols4_tall(const float4* __restrict__ v, float4* out, int rows, int cols4, float sT, float sO,
+                                                          SumSeg2 two) {
     __shared__ float4 sh[16][17];
     const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cg;
+    int blk = blockIdx.x;
+    if (two.nb1 && blk >= two.nb1) {
+        v = two.v; out = two.out; cols4 = two.cols4; sT = 0.f; sO = two.sO;
+        blk -= two.nb1;
+    }
+    const int c = blk * 16 + cg;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < cols4)
         for (int r = rg; r < rows; r += 16) {
@@ -582,14 +602,38 @@ __global__ void __launch_bounds__(256) k_sum_cols4_tall(const float4* __restrict
     }
 }
 
+// out1 = sT1 * out1 + sO1 * column sums of v1 (rows x cols1) and out2 = sO2 * column sums of v2 (rows x cols2), one launch
+// when both are float4-shaped, else two.
+// tallMin: from how many rows on the sum is split over 16 row groups (the callers keep the summation order of the kernel their
+// unfused variant uses, so fused and unfused weight gradients agree bit for bit)
+int mc__sum_cols_pair(const float* v1, float* out1, int cols1, float sT1, float sO1, const float* v2, float* out2, int cols2, float sO2, int rows,
+                      int tallMin, hipStream_t st) {
+    if (cols1 % 4 || cols2 % 4 || !aligned16(v1) || !aligned16(out1) || !aligned16(v2) || !aligned16(out2)) {
+        const int rc = mc_sum_cols(v1, out1, rows, cols1, sT1, sO1, reinterpret_cast<mcStream_t>(st));
+        return rc ? rc : mc_sum_cols(v2, out2, rows, cols2, 0.f, sO2, reinterpret_cast<mcStream_t>(st));
+    }
+    SumSeg2 two{reinterpret_cast<const float4*>(v2), reinterpret_cast<float4*>(out2), cols2 / 4, sO2, 0};
+    if (rows >= tallMin) {
+        two.nb1 = ceil_div(cols1 / 4, 16);
+        hipLaunchKernelGGL(k_sum_cols4_tall, dim3(two.nb1 + ceil_div(cols2 / 4, 16)), dim3(256), 0, st, reinterpret_cast<const float4*>(v1),
+                           reinterpret_cast<float4*>(out1), rows, cols1 / 4, sT1, sO1, two);
+    } else {
+        two.nb1 = grid_for(cols1 / 4);
+        hipLaunchKernelGGL(k_sum_cols4, dim3(two.nb1 + grid_for(cols2 / 4)), dim3(TPB), 0, st, reinterpret_cast<const float4*>(v1),
+                           reinterpret_cast<float4*>(out1), rows, cols1 / 4, sT1, sO1, two);
+    }
+    return launch_status("mc_sum_cols(pair)");
+}
+
 int mc_sum_cols(const float* v, float* out, int rows, int cols, float sT, float sO, mcStream_t s) {
     MC_REQUIRE(v && out && rows > 0 && cols > 0, "mc_sum_cols: bad arguments");
+    const SumSeg2 none{nullptr, nullptr, 0, 0.f, 0};
     if (cols % 4 == 0 && aligned16(v) && aligned16(out) && rows >= 32)
         hipLaunchKernelGGL(k_sum_cols4_tall, dim3(ceil_div(cols / 4, 16)), dim3(256), 0, S(s), reinterpret_cast<const float4*>(v),
-                           reinterpret_cast<float4*>(out), rows, cols / 4, sT, sO);
+                           reinterpret_cast<float4*>(out), rows, cols / 4, sT, sO, none);
     else if (cols % 4 == 0 && aligned16(v) && aligned16(out))
         hipLaunchKernelGGL(k_sum_cols4, dim3(grid_for(cols / 4)), dim3(TPB), 0, S(s), reinterpret_cast<const float4*>(v),
-                           reinterpret_cast<float4*>(out), rows, cols / 4, sT, sO);
+                           reinterpret_cast<float4*>(out), rows, cols / 4, sT, sO, none);
     else
         hipLaunchKernelGGL(k_sum_cols, dim3(grid_for(cols)), dim3(TPB), 0, S(s), v, out, rows, cols, sT, sO);
     return launch_status("mc_sum_cols");

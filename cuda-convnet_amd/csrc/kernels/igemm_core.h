@@ -113,6 +113,13 @@ struct Epi {
     unsigned* bitsOut;        // nullable: written by the epilogue, bit = (output > 0)
     const unsigned* bitsIn;   // EPI_BITS kernels: outputs whose bit is clear are written as 0 (relu gradient)
     unsigned wBytes;          // extent of the bit matrix in bytes
+    // Sum of one operand over k, a by-product of kernels whose A or B loader is tagged SUM (weight gradients: the operand is
+    // the layer's output gradient, its sum over k the bias gradient): chunk q writes sumAlpha * sum_k op(k, x) to
+    // sumOut[q * sumStride + x + g * (rowG | colG)].  Nullable.  Each lane adds the k values it feeds to the MFMAs anyway,
+    // in k order, so the result does not depend on the tile shape.
+    float* sumOut;
+    long sumStride;
+    float sumAlpha;
 };
 // Epilogue flavours (a template parameter: as run-time branches inside one kernel the variants that load cost every
 // instantiation 40-80 registers, i.e. a resident workgroup per CU):
@@ -163,6 +170,16 @@ struct MatKcAddr {
     }
     __device__ static __forceinline__ const float* base(const P& p) { return p.p; }
 };
+
+// MatKcAddr whose sum over k the kernel also delivers (Epi::sumOut)
+struct MatKcSumAddr : MatKcAddr {
+    static const char* tag() { return "MatKcSumAddr"; }
+    static constexpr bool SUM = true;
+};
+template <class T, class = void>
+struct has_sum : std::false_type {};
+template <class T>
+struct has_sum<T, std::void_t<decltype(T::SUM)>> : std::true_type {};
 
 struct ConvP {
     const float* p;
@@ -453,7 +470,8 @@ __device__ __forceinline__ void lds_done_barrier() {
 template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC, int NS, int EPI, int KQ>
 __global__ void __launch_bounds__(2 * THREADS)
 #ifndef MC_NO_T51_CAP   // the 160-row tile sits 3-17 registers above 128 = two resident workgroups per CU: cap it (a few spills outside the K loop)
-__attribute__((amdgpu_waves_per_eu((MT == 5 && NT == 1) ? 4 : 1)))
+// (not the weight-gradient kernels: their k-contiguous tiles leave LDS for one workgroup per CU, and at 128 registers they spill 300-500)
+__attribute__((amdgpu_waves_per_eu((MT == 5 && NT == 1 && !(AADDR::KC && BADDR::KC)) ? 4 : 1)))
 #endif
 mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     static_assert(WM * WN * KQ == 4 && (KQ == 1 || KQ == 2), "4 consumer waves");
@@ -608,6 +626,9 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     const int wm = w2 / WN, wn = w2 % WN;
 
     f32x16 acc[MT][NT];
+    constexpr bool SUMA = has_sum<AADDR>::value && KQ == 1, SUMB = has_sum<BADDR>::value && KQ == 1;
+    float rs[MT], cs[NT];   // SUMA / SUMB: this lane's share of the k-sums of its A rows / B columns
+    (void)rs; (void)cs;
 
     // LDS -> register fragments, software-pipelined ACROSS K steps: "slab" s holds the operands of one
     // MFMA k-step (2 k values: lane half h supplies k = kof(s) + h-dependent offset).  The reads of slab
@@ -790,6 +811,14 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         for (int b = 0; b < NT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    if constexpr (SUMA) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a) rs[a] = 0.f;
+    }
+    if constexpr (SUMB) {
+#pragma unroll
+        for (int b = 0; b < NT; ++b) cs[b] = 0.f;
+    }
     for (int t = 0; t < nkTile; ++t) {
         const int nstage = stage == 2 ? 0 : stage + 1;
         STAMP(c0);
@@ -807,6 +836,14 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s_][a], bf[s_][b], acc[a][b], 0, 0, 0);
+            if constexpr (SUMA) {   // a handful of adds under MT * NT matrix instructions of 64 cycles each
+#pragma unroll
+                for (int a = 0; a < MT; ++a) rs[a] += af[s_][a];
+            }
+            if constexpr (SUMB) {
+#pragma unroll
+                for (int b = 0; b < NT; ++b) cs[b] += bf[s_][b];
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         // end of K step t.  No LDS wait here: every read of this stage has been consumed by an MFMA above,
@@ -846,6 +883,27 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
                 for (int r = 0; r < 16; ++r) acc[a][b][r] += red[((a * NT + b) * 16 + r) * 64 + lane];
             }
         __builtin_amdgcn_sched_barrier(0);
+    }
+    // k-sums: the two lane halves hold alternate groups of four k values; waves that share the operand hold copies
+    if constexpr (SUMA) {
+        if (ep.sumOut) {
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const float v = rs[a] + __shfl_xor(rs[a], 32);
+                const int i = i0 + (wm * MT + a) * 32 + l31;
+                if (ct == 0 && wn == 0 && h == 0 && i < ilim) ep.sumOut[q * ep.sumStride + i + g * ep.rowG] = ep.sumAlpha * v;
+            }
+        }
+    }
+    if constexpr (SUMB) {
+        if (ep.sumOut) {
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const float v = cs[b] + __shfl_xor(cs[b], 32);
+                const int j = coff + col_block(ct) * BN + (wn * NT + b) * 32 + l31;
+                if (blockIdx.y == 0 && wm == 0 && h == 0 && j < jlim) ep.sumOut[q * ep.sumStride + j + g * ep.colG] = ep.sumAlpha * v;
+            }
+        }
     }
     // this tile's K loop is complete: store it while the producers run ahead into the next tile
     STAMP(s0);
@@ -1013,7 +1071,7 @@ int launch_rows_cols_epi(const typename AADDR::P& pa, const typename BADDR::P& p
         for (auto& m : map)
             if (forced[0] - '0' == m[0] && forced[2] - '0' == m[1]) return launch_tile<AADDR, BADDR, BK, VEC, EPI>(m[2], pa, pb, cg, d, ep, chunks, st);
     }
-    const int rule = heuristic_tile(d, chunks, BK == 32 && EPI == EPI_PLAIN);
+    const int rule = heuristic_tile(d, chunks, BK == 32 && EPI == EPI_PLAIN && !ep.sumOut);   // (the K-split tile has no k-sums)
     if (rule == T33K) return launch_tile<AADDR, BADDR, BK, VEC, EPI>(rule, pa, pb, cg, d, ep, chunks, st);   // by rule only: its sum order is its own
     static const char* at = getenv("MC_IGEMM_AUTOTUNE");
     static const int mode = at ? atoi(at) : 1;

@@ -9,7 +9,7 @@ MC_STAMP_API(gemm)
 // =================================================================================
 int gemm_impl(const float* A, const float* B, float* Cm, int m, int n, int k, int transA, int transB, int lda, int ldb,
               int ldc, float beta, float alpha, const float* rowBias, int neuron, const float* mask, int ldmask, int chunks,
-              long chunkStride, unsigned* bitsOut, const unsigned* bitsIn, hipStream_t st) {
+              long chunkStride, unsigned* bitsOut, const unsigned* bitsIn, float* sumOut, long sumStride, float sumAlpha, hipStream_t st) {
     ConvG cg{};
     int kChunk = k;
     if (chunks > 1) {
@@ -23,6 +23,13 @@ int gemm_impl(const float* A, const float* B, float* Cm, int m, int n, int k, in
     ep.bitsOut = bitsOut;
     ep.bitsIn = bitsIn;
     ep.wBytes = (unsigned)(((size_t)(ceil_div(m, 32) - 1) * ldc + n) * 4);
+    if (sumOut && !(!transA && transB)) {
+        set_error("mc_gemm: row sums of A come with the weight-gradient orientation (transA = 0, transB = 1) only");
+        return MC_EINVAL;
+    }
+    ep.sumOut = sumOut;   // by-product: chunk q's sum of A over its k range, per row
+    ep.sumStride = sumStride;
+    ep.sumAlpha = sumAlpha;
     // operand extents in bytes: (rows - 1) * ld + row length
     const size_t ea = transA ? (size_t)(k - 1) * lda + m : (size_t)(m - 1) * lda + k;
     const size_t eb = transB ? (size_t)(n - 1) * ldb + k : (size_t)(k - 1) * ldb + n;
@@ -40,8 +47,8 @@ int gemm_impl(const float* A, const float* B, float* Cm, int m, int n, int k, in
     if (transA && !transB) return MC_GEMM_CASE(MatNatAddr, MatNatAddr, true, false);
     if (!transA && !transB) return MC_GEMM_CASE(MatKcAddr, MatNatAddr, false, true);
     if (!transA && transB)
-        return vec ? launch_rows_cols<MatKcAddr, MatKcAddr, MC_BK_KC, 4>(pa, pb, cg, d, ep, chunks, st)
-                   : launch_rows_cols<MatKcAddr, MatKcAddr, MC_BK_KC, 1>(pa, pb, cg, d, ep, chunks, st);
+        return vec ? launch_rows_cols<MatKcSumAddr, MatKcAddr, MC_BK_KC, 4>(pa, pb, cg, d, ep, chunks, st)
+                   : launch_rows_cols<MatKcSumAddr, MatKcAddr, MC_BK_KC, 1>(pa, pb, cg, d, ep, chunks, st);
     return MC_GEMM_CASE(MatNatAddr, MatKcAddr, false, false);
 #undef MC_GEMM_CASE
 }

@@ -9,7 +9,7 @@ MC_STAMP_API(wgrad)
 // =================================================================================
 int conv_weight_acts_impl(const float* images, const float* hidActs, float* targets, int N, int C, int H, int W, int F,
                           int fs, int pad, int stride, int MY, int MX, int groups, int partialSum, int kChunk, float scaleTargets,
-                          float scaleOutput, hipStream_t st) {
+                          float scaleOutput, float* sumOut, long sumStride, float sumAlpha, hipStream_t st) {
     ConvG cg;
     int rc = make_convg(cg, N, C, H, W, F, fs, pad, stride, MY, MX, groups, 0, "convWeightActs");
     if (rc) return rc;
@@ -26,11 +26,15 @@ int conv_weight_acts_impl(const float* images, const float* hidActs, float* targ
     }
     Dims d{cg.fc * cg.fp, cg.fpg, cg.M * N, kChunk, groups, 0, 0, 1, 0};
     Epi ep{targets, F, 0, cg.fpg, (long)cg.fc * cg.fp * F, scaleOutput, scaleTargets, nullptr, MC_NEURON_NONE, nullptr, 0, (unsigned)((size_t)cg.fc * cg.fp * F * 4), 0};
+    // by-product: chunk q's sum of hidActs over its (module, image) range, per filter -- the shared-bias gradient
+    ep.sumOut = sumOut;
+    ep.sumStride = sumStride;
+    ep.sumAlpha = sumAlpha;
     ConvP pa{images, cg.fc * cg.fp, (unsigned)((size_t)C * H * W * N * 4)};
     MatP pb{hidActs, cg.M * N, cg.fpg, cg.fpg * cg.M * N, (unsigned)((size_t)F * cg.M * N * 4), 0};  // hid[(g*fpg+f)*M*N + k]
     const bool vec = (N % 4 == 0) && aligned16(images) && aligned16(hidActs);
-    if (vec) return launch_rows_cols<PatchKcAddr, MatKcAddr, MC_BK_KC, 4>(pa, pb, cg, d, ep, chunks, st);
-    return launch_rows_cols<PatchKcAddr, MatKcAddr, MC_BK_KC, 1>(pa, pb, cg, d, ep, chunks, st);
+    if (vec) return launch_rows_cols<PatchKcAddr, MatKcSumAddr, MC_BK_KC, 4>(pa, pb, cg, d, ep, chunks, st);
+    return launch_rows_cols<PatchKcAddr, MatKcSumAddr, MC_BK_KC, 1>(pa, pb, cg, d, ep, chunks, st);
 }
 
 // Chunking of the (module, image) axis for mc_conv_weight_grad: as many chunks as keep about one workgroup per CU

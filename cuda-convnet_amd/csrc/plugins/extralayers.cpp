@@ -87,16 +87,24 @@ protected:
         RT_MC(mc_sum_rows(v.data(), _biases->getGrad(), _channels * _out, P * N, 0.f, scale, ST()));
     }
 
-    void bpropWeights(DevMat& v, int inpIdx, PASS_TYPE passType) override {
+    bool fusesBiasGrad() const override { return true; }
+
+    void bpropWeights(DevMat& v, int inpIdx, PASS_TYPE passType, bool withBiases = false) override {
         const int N = numCases(), P = pixels(_prev[inpIdx]->getNumOutputs()), cols = P * N;
         const float scale = passType == PASS_GC ? 1.f : _weights[inpIdx].getEps() / _convNet->gradScaleCases(N);
+        const float bscale = passType == PASS_GC ? 1.f : _biases->getEps() / _convNet->gradScaleCases(N);
         const float scaleTargets = _weights[inpIdx].getNumUpdates() > 0 ? 1.f : 0.f;
-        const size_t wsb = mc_gemm_workspace_bytes(_out, _in, cols);
+        const size_t wsb = withBiases ? mc_gemm_row_sums_workspace_bytes(_out, _in, cols) : mc_gemm_workspace_bytes(_out, _in, cols);
         for (int ch = 0; ch < _channels; ch++) {
             const float* G = v.data() + (size_t)ch * _out * cols;
             const float* X = _prev[inpIdx]->getActs().data() + (size_t)ch * _in * cols;
             float* dW = _weights[inpIdx].getGrad() + (size_t)ch * _out * _in;
-            // dW(out, in) = G(out, P*N) * X(in, P*N)^T
+            // dW(out, in) = G(out, P*N) * X(in, P*N)^T; with the biases, db(out) = the row sums of G from the same pass
+            if (withBiases) {
+                RT_MC(mc_gemm_row_sums(G, X, dW, _out, _in, cols, cols, cols, _in, scaleTargets, scale, _biases->getGrad() + (size_t)ch * _out, bscale,
+                                       wsb ? workspace(wsb) : nullptr, wsb, ST()));
+                continue;
+            }
             RT_MC(mc_gemm(G, X, dW, _out, _in, cols, 0, 1, cols, cols, _in, scaleTargets, scale, nullptr, MC_NEURON_NONE, wsb ? workspace(wsb) : nullptr, wsb, ST()));
         }
     }

@@ -394,14 +394,20 @@ WeightLayer::WeightLayer(ConvNet* convNet, PyObject* paramsDict, bool deviceFort
 }
 
 void WeightLayer::bpropCommon(DevMat& v, PASS_TYPE passType) {
-    if (_biases->getEps() > 0) {
+    // The weight-gradient product of input 0 reads all of v; layers that can have it deliver the bias gradient (a sum
+    // over v) from that pass instead of reading v once more (MC_NO_FUSED_BIAS=1: the separate reduction, for A/B runs).
+    static const bool noFuse = getenv("MC_NO_FUSED_BIAS") != nullptr;
+    const bool biases = _biases->getEps() > 0;
+    const bool fused = biases && !noFuse && fusesBiasGrad() && _weights.getSize() > 0 && _weights[0].getEps() > 0;
+    if (biases && !fused) {
         bpropBiases(v, passType);
         _convNet->gradientReady(*_biases);
     }
     for (int i = 0; i < _weights.getSize(); i++) {
         if (_weights[i].getEps() > 0) {
-            bpropWeights(v, i, passType);
+            bpropWeights(v, i, passType, fused && i == 0);
             _weights[i].incNumUpdates();
+            if (fused && i == 0) _convNet->gradientReady(*_biases);
             _convNet->gradientReady(_weights[i]);
         }
     }
@@ -490,12 +496,19 @@ void FCLayer::bpropBiases(DevMat& v, PASS_TYPE passType) {
     RT_MC(mc_sum_rows(v.data(), _biases->getGrad(), _numOutputs, numCases(), 0.f, scale, ST()));
 }
 
-void FCLayer::bpropWeights(DevMat& v, int inpIdx, PASS_TYPE passType) {
+void FCLayer::bpropWeights(DevMat& v, int inpIdx, PASS_TYPE passType, bool withBiases) {
     const int N = numCases(), in = _prev[inpIdx]->getNumOutputs(), out = _numOutputs;
     const float scale = passType == PASS_GC ? 1.f : _weights[inpIdx].getEps() / _convNet->gradScaleCases(N);
     const float scaleTargets = _weights[inpIdx].getNumUpdates() > 0 ? 1.f : 0.f;
-    const size_t wsb = mc_gemm_workspace_bytes(out, in, N);
     // dW(out, in) = g(out, N) * x(in, N)^T
+    if (withBiases) {   // ... and db(out) = the row sums of g
+        const float bscale = passType == PASS_GC ? 1.f : _biases->getEps() / _convNet->gradScaleCases(N);
+        const size_t wsb = mc_gemm_row_sums_workspace_bytes(out, in, N);
+        RT_MC(mc_gemm_row_sums(v.data(), _prev[inpIdx]->getActs().data(), _weights[inpIdx].getGrad(), out, in, N, N, N, in, scaleTargets, scale,
+                               _biases->getGrad(), bscale, wsb ? workspace(wsb) : nullptr, wsb, ST()));
+        return;
+    }
+    const size_t wsb = mc_gemm_workspace_bytes(out, in, N);
     RT_MC(mc_gemm(v.data(), _prev[inpIdx]->getActs().data(), _weights[inpIdx].getGrad(), out, in, N, 0, 1, N, N, in, scaleTargets, scale, nullptr,
                   MC_NEURON_NONE, wsb ? workspace(wsb) : nullptr, wsb, ST()));
 }
@@ -627,7 +640,7 @@ void ConvLayer::bpropBiases(DevMat& v, PASS_TYPE passType) {
     else RT_MC(mc_sum_rows(v.data(), _biases->getGrad(), _numFilters * _modules, numCases(), 0.f, scale, ST()));
 }
 
-void ConvLayer::bpropWeights(DevMat& v, int i, PASS_TYPE passType) {
+void ConvLayer::bpropWeights(DevMat& v, int i, PASS_TYPE passType, bool withBiases) {
     // The reference sums `partialSum` modules per chunk into a temporary and then reduces the
     // chunks (layer.cu:503-523).  Same structure; the chunking is chosen for this device rather
     // than read from the layer file (the sum is the same, only its association differs), and the
@@ -638,6 +651,14 @@ void ConvLayer::bpropWeights(DevMat& v, int i, PASS_TYPE passType) {
                                                            _modules, _groups->at(i));
     // a sparse input was gathered by fpropActs; the gathered tensor is the layer's own and still holds this minibatch
     const float* in = sparse(i) ? _gathered[i]->data() : _prev[i]->getActs().data();
+    if (withBiases) {   // per-filter biases: their gradient is the sum of v over modules and cases, which this product reads anyway
+        const float bscale = passType == PASS_GC ? 1.f : _biases->getEps() / _convNet->gradScaleCases(numCases());
+        const size_t wsbb = mc_conv_weight_grad_bias_workspace_bytes(numCases(), sparse(i) ? sparseChannels(i) : _channels->at(i), _numFilters,
+                                                                     _filterSize->at(i), _modules, _groups->at(i));
+        RT_MC(mc_conv_weight_grad_bias(in, v.data(), _weights[i].getGrad(), _biases->getGrad(), CONV_GEOM(i), scaleTargets, scale, bscale,
+                                       wsbb ? workspace(wsbb) : nullptr, wsbb, ST()));
+        return;
+    }
     RT_MC(mc_conv_weight_grad(in, v.data(), _weights[i].getGrad(), CONV_GEOM(i), scaleTargets, scale,
                               wsb ? workspace(wsb) : nullptr, wsb, ST()));
 }
@@ -666,7 +687,7 @@ void LocalUnsharedLayer::bpropBiases(DevMat& v, PASS_TYPE passType) {
     RT_MC(mc_sum_rows(v.data(), _biases->getGrad(), _numFilters * _modules, numCases(), 0.f, scale, ST()));
 }
 
-void LocalUnsharedLayer::bpropWeights(DevMat& v, int i, PASS_TYPE passType) {
+void LocalUnsharedLayer::bpropWeights(DevMat& v, int i, PASS_TYPE passType, bool) {
     const float scale = passType == PASS_GC ? 1.f : _weights[i].getEps() / _convNet->gradScaleCases(numCases());
     const float scaleTargets = _weights[i].getNumUpdates() > 0 ? 1.f : 0.f;
     const float* in = sparse(i) ? _gathered[i]->data() : _prev[i]->getActs().data();

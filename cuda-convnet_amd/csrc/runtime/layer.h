@@ -236,7 +236,10 @@ public:
 protected:
     void bpropCommon(DevMat& v, PASS_TYPE passType) override;   // layer.cu:318-334
     virtual void bpropBiases(DevMat& v, PASS_TYPE passType) = 0;
-    virtual void bpropWeights(DevMat& v, int inpIdx, PASS_TYPE passType) = 0;
+    // withBiases: also deliver the bias gradient, from the same pass over `v` (asked only of layers whose
+    // fusesBiasGrad() is true, for input 0, and instead of bpropBiases)
+    virtual void bpropWeights(DevMat& v, int inpIdx, PASS_TYPE passType, bool withBiases = false) = 0;
+    virtual bool fusesBiasGrad() const { return false; }
     // If the only consumer is an in-place plain relu, returns it (epilogue fusion candidate).
     NeuronLayer* fusableRelu();
     // scratch for split-K / partial sums, shared by all layers of the net
@@ -251,12 +254,13 @@ class FCLayer : public WeightLayer {
 public:
     FCLayer(ConvNet* convNet, PyObject* paramsDict);
     bool readsReluBits(int rows, int ld, int numCases) const override { return ld == numCases; }   // its view: (features, cases)
+    bool fusesBiasGrad() const override { return true; }
 
 protected:
     void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
     void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
     void bpropBiases(DevMat& v, PASS_TYPE passType) override;
-    void bpropWeights(DevMat& v, int inpIdx, PASS_TYPE passType) override;
+    void bpropWeights(DevMat& v, int inpIdx, PASS_TYPE passType, bool withBiases = false) override;
 };
 
 class LocalLayer : public WeightLayer {
@@ -288,12 +292,13 @@ class ConvLayer : public LocalLayer {
 public:
     ConvLayer(ConvNet* convNet, PyObject* paramsDict);
     size_t splitWorkspaceBytes(int numCases) const override;
+    bool fusesBiasGrad() const override { return _sharedBiases; }   // per-filter biases: the sum of v over modules and cases
 
 protected:
     void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
     void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
     void bpropBiases(DevMat& v, PASS_TYPE passType) override;
-    void bpropWeights(DevMat& v, int inpIdx, PASS_TYPE passType) override;
+    void bpropWeights(DevMat& v, int inpIdx, PASS_TYPE passType, bool withBiases = false) override;
     int _partialSum;
     bool _sharedBiases;
 };
@@ -306,7 +311,7 @@ protected:
     void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
     void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
     void bpropBiases(DevMat& v, PASS_TYPE passType) override;
-    void bpropWeights(DevMat& v, int inpIdx, PASS_TYPE passType) override;
+    void bpropWeights(DevMat& v, int inpIdx, PASS_TYPE passType, bool withBiases = false) override;
 };
 
 class SoftmaxLayer : public Layer {

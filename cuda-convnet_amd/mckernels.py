@@ -31,6 +31,8 @@ _SIGS = {
     "mc_gemm": [c_fp, c_fp, c_fp] + [c_i] * 8 + [c_f, c_f, c_fp, c_i, c_fp, c_sz, c_fp],
     "mc_conv_weight_grad": [c_fp, c_fp, c_fp] + [c_i] * 11 + [c_f, c_f, c_fp, c_sz, c_fp],
     "mc_conv_weight_grad_noalloc": [c_fp, c_fp, c_fp] + [c_i] * 11 + [c_f, c_f, c_fp],
+    "mc_conv_weight_grad_bias": [c_fp, c_fp, c_fp, c_fp] + [c_i] * 11 + [c_f, c_f, c_f, c_fp, c_sz, c_fp],
+    "mc_gemm_row_sums": [c_fp, c_fp, c_fp] + [c_i] * 6 + [c_f, c_f, c_fp, c_f, c_fp, c_sz, c_fp],
     "mc_reserve_conv_split_workspace": [c_sz, c_fp],
     "mc_conv_filter_acts_relu_bits": [c_fp] * 5 + [c_i] * 10 + [c_fp],
     "mc_gemm_relu_bits": [c_fp, c_fp, c_fp] + [c_i] * 8 + [c_fp, c_fp, c_fp],
@@ -97,7 +99,8 @@ class McError(RuntimeError):
 def exported_symbols():
     """Names every build of the library must export (those include/mc_kernels.h declares)."""
     return sorted(list(_SIGS) + ["mc_last_error", "mc_gemm_workspace_bytes", "mc_conv_weight_grad_workspace_bytes",
-                                   "mc_noalloc_scratch_bytes", "mc_conv_split_workspace_bytes", "mc_relu_bits_words"])
+                                   "mc_noalloc_scratch_bytes", "mc_conv_split_workspace_bytes", "mc_relu_bits_words",
+                                   "mc_conv_weight_grad_bias_workspace_bytes", "mc_gemm_row_sums_workspace_bytes"])
 
 
 def lib():
@@ -116,6 +119,10 @@ def lib():
         L.mc_gemm_workspace_bytes.restype = c_sz
         L.mc_conv_weight_grad_workspace_bytes.argtypes = [c_i] * 6
         L.mc_conv_weight_grad_workspace_bytes.restype = c_sz
+        L.mc_conv_weight_grad_bias_workspace_bytes.argtypes = [c_i] * 6
+        L.mc_conv_weight_grad_bias_workspace_bytes.restype = c_sz
+        L.mc_gemm_row_sums_workspace_bytes.argtypes = [c_i, c_i, c_i]
+        L.mc_gemm_row_sums_workspace_bytes.restype = c_sz
         L.mc_noalloc_scratch_bytes.argtypes = []
         L.mc_noalloc_scratch_bytes.restype = c_sz
         L.mc_relu_bits_words.argtypes = [c_i, c_i]

@@ -102,6 +102,18 @@ int mc_conv_weight_grad(const float* images, const float* hidActs, float* weight
                         int paddingStart, int moduleStride, int numModulesY, int numModulesX,
                         int numGroups, float scaleTargets, float scaleOutput, void* workspace,
                         size_t workspaceBytes, mcStream_t stream);
+/* ConvLayer::bpropBiases + bpropWeights in one pass over hidActs (layer.cu:489-523): the weight-gradient product reads every
+ * element of hidActs anyway, so the gradient of biases shared per filter -- the reference's separate
+ * `_biases->getGrad().addSum(v reshaped (numFilters, modules*images), 1, ...)`, layer.cu:491-497 -- comes out of the same kernel:
+ * biasGrad[f] = biasScale * sum over modules and images of hidActs[f] (overwritten), weightGrad as mc_conv_weight_grad.
+ * The sum is formed in a fixed order that depends on the shape only.  workspace: mc_conv_weight_grad_bias_workspace_bytes. */
+size_t mc_conv_weight_grad_bias_workspace_bytes(int numImages, int numImgColors, int numFilters,
+                                                int filterSize, int numModules, int numGroups);
+int mc_conv_weight_grad_bias(const float* images, const float* hidActs, float* weightGrad, float* biasGrad,
+                             int numImages, int numImgColors, int imgSizeY, int imgSizeX, int numFilters,
+                             int filterSize, int paddingStart, int moduleStride, int numModulesY,
+                             int numModulesX, int numGroups, float scaleTargets, float scaleOutput,
+                             float biasScale, void* workspace, size_t workspaceBytes, mcStream_t stream);
 
 /* mc_conv_weight_grad for callers that cannot allocate device memory or hand over a workspace: code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE.  The split-K slabs live
@@ -156,6 +168,14 @@ size_t mc_gemm_workspace_bytes(int m, int n, int k);
 int mc_gemm(const float* A, const float* B, float* C, int m, int n, int k, int transA, int transB,
             int lda, int ldb, int ldc, float scaleTargets, float scaleOutput, const float* rowBias,
             int neuron, void* workspace, size_t workspaceBytes, mcStream_t stream);
+/* The weight-gradient orientation, C(m,n) = scaleTargets*C + scaleOutput * A(m,k) * B(n,k)^T, that also delivers
+ * rowSums[i] = sumScale * sum_k A(i,k) (overwritten) from the same pass over A: FCLayer / CCCPLayer bpropBiases
+ * (layer.cu:397-400 `addSum(v, 1, ...)`, extralayers.cu:130-138) fused into bpropWeights (layer.cu:402-409,
+ * extralayers.cu:140-174), where A is the layer's output gradient.  workspace: mc_gemm_row_sums_workspace_bytes. */
+size_t mc_gemm_row_sums_workspace_bytes(int m, int n, int k);
+int mc_gemm_row_sums(const float* A, const float* B, float* C, int m, int n, int k, int lda, int ldb, int ldc,
+                     float scaleTargets, float scaleOutput, float* rowSums, float sumScale, void* workspace,
+                     size_t workspaceBytes, mcStream_t stream);
 /* The same product with the gradient mask of a relu fused into the store: every written element whose
  * reluActs(i, j) (row stride ldr) is not > 0 becomes 0.  Replaces the pair
  * FCLayer/CCCPLayer::bpropActs (layer.cu:380-384, extralayers.cu:103-124) + ReluNeuron's gradient

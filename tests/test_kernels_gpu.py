@@ -508,6 +508,74 @@ def test_conv_weight_grad_free_chunking(N, C, H, fs, F, pad, stride, groups):
     assert np.array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("N,C,H,fs,F,pad,stride,groups", [(128, 32, 16, 5, 32, 2, 1, 1), (128, 3, 32, 5, 192, 2, 1, 1), (32, 96, 8, 5, 192, 2, 1, 1),
+                                                         (128, 192, 8, 3, 192, 1, 1, 1), (12, 8, 9, 3, 16, 1, 2, 2), (5, 3, 10, 5, 4, 0, 1, 1),
+                                                         (7, 16, 12, 3, 160, 1, 1, 1)])
+def test_conv_weight_grad_with_bias_gradient(N, C, H, fs, F, pad, stride, groups):
+    """mc_conv_weight_grad_bias: the weight gradient is bit-identical to mc_conv_weight_grad's, and the per-filter bias
+    gradient equals ConvLayer::bpropBiases' row sum of hidActs viewed (numFilters, modules * images) (layer.cu:491-497)."""
+    m = mc()
+    rng = np.random.default_rng(47)
+    M = _modules(H, fs, pad, stride)
+    img = rng.standard_normal((C * H * H, N)).astype(np.float32)
+    hid = (rng.standard_normal((F * M * M, N)) + 0.25).astype(np.float32)
+    geo = (N, C, H, H, F, fs, -pad, stride, M, M, groups)
+    dimg, dhid = dev(img), dev(hid)
+    wsb = m.lib().mc_conv_weight_grad_workspace_bytes(N, C, F, fs, M * M, groups)
+    ws = nans(max(1, wsb // 4))
+    wshape = ((C // groups) * fs * fs, F)
+    ref = nans(*wshape)
+    m.call("mc_conv_weight_grad", ptr(dimg), ptr(dhid), ptr(ref), *geo, 0.0, 0.01, ptr(ws), wsb, None)
+    wsbb = m.lib().mc_conv_weight_grad_bias_workspace_bytes(N, C, F, fs, M * M, groups)
+    assert (wsbb == 0) == (wsb == 0) and wsbb >= wsb
+    wsB = nans(max(1, wsbb // 4))
+    outs = []
+    for _ in range(2):
+        dw, dbias = nans(*wshape), nans(F, 1)
+        m.call("mc_conv_weight_grad_bias", ptr(dimg), ptr(dhid), ptr(dw), ptr(dbias), *geo, 0.0, 0.01, 0.5, ptr(wsB), wsbb, None)
+        outs.append((host(dw), host(dbias)))
+    assert np.array_equal(outs[0][0], host(ref))
+    expb = 0.5 * hid.astype(np.float64).reshape(F, M * M * N).sum(axis=1)
+    assert relerr(outs[0][1][:, 0], expb) < TOL
+    assert np.array_equal(outs[0][1], outs[1][1])                    # a fixed summation order: run-to-run identical
+    # accumulating weights (a matrix shared by two layers) still overwrite the bias gradient
+    prev = rng.standard_normal(wshape).astype(np.float32)
+    dw, dbias = dev(prev), nans(F, 1)
+    m.call("mc_conv_weight_grad_bias", ptr(dimg), ptr(dhid), ptr(dw), ptr(dbias), *geo, 1.0, 0.01, 0.5, ptr(wsB), wsbb, None)
+    assert relerr(host(dw), prev + host(ref).astype(np.float64)) < TOL and np.array_equal(host(dbias), outs[0][1])
+
+
+@pytest.mark.parametrize("m_,n_,k_", [(160, 192, 131072), (96, 160, 131072), (192, 192, 32768), (10, 192, 8192), (192, 96, 1000), (37, 53, 29),
+                                      (64, 4096, 128), (1000, 2048, 128)])
+def test_gemm_row_sums(m_, n_, k_):
+    """mc_gemm_row_sums: C = A . B^T bit-identical to mc_gemm(transB) and rowSums = sumScale * row sums of A (the bias gradient
+    of FCLayer / CCCPLayer, layer.cu:397-400, extralayers.cu:130-138), split-K (long k) and unsplit shapes."""
+    m = mc()
+    rng = np.random.default_rng(53)
+    A = (rng.standard_normal((m_, k_)) + 0.125).astype(np.float32)
+    B = rng.standard_normal((n_, k_)).astype(np.float32)
+    dA, dB = dev(A), dev(B)
+    wsb = m.lib().mc_gemm_workspace_bytes(m_, n_, k_)
+    ws = nans(max(1, wsb // 4))
+    ref = nans(m_, n_)
+    m.call("mc_gemm", ptr(dA), ptr(dB), ptr(ref), m_, n_, k_, 0, 1, k_, k_, n_, 0.0, 0.5, None, m.NEURON_NONE, ptr(ws), wsb, None)
+    wsr = m.lib().mc_gemm_row_sums_workspace_bytes(m_, n_, k_)
+    assert (wsr == 0) == (wsb == 0) and wsr >= wsb
+    wsR = nans(max(1, wsr // 4))
+    outs = []
+    for _ in range(2):
+        C, sums = nans(m_, n_), nans(m_, 1)
+        m.call("mc_gemm_row_sums", ptr(dA), ptr(dB), ptr(C), m_, n_, k_, k_, k_, n_, 0.0, 0.5, ptr(sums), 0.25, ptr(wsR), wsr, None)
+        outs.append((host(C), host(sums)))
+    assert np.array_equal(outs[0][0], host(ref))
+    assert relerr(outs[0][1][:, 0], 0.25 * A.astype(np.float64).sum(axis=1)) < TOL
+    assert np.array_equal(outs[0][1], outs[1][1])
+    # without a workspace the unsplit product delivers the same values to tolerance
+    C, sums = nans(m_, n_), nans(m_, 1)
+    m.call("mc_gemm_row_sums", ptr(dA), ptr(dB), ptr(C), m_, n_, k_, k_, k_, n_, 0.0, 0.5, ptr(sums), 0.25, None, 0, None)
+    assert relerr(host(C), host(ref)) < TOL and relerr(host(sums)[:, 0], 0.25 * A.astype(np.float64).sum(axis=1)) < TOL
+
+
 # ---------------------------------------------------------------------------------------------------------
 # relu bit masks (include/mc_kernels.h "relu bit masks"): written by forward products, read by backward products
 # ---------------------------------------------------------------------------------------------------------
