@@ -41,6 +41,7 @@ int conv_weight_acts_impl(const float*, const float*, float*, int, int, int, int
                           float, float, float*, long, float, hipStream_t);
 int conv_weight_grad_plan(int, int, int, int, int, int, int*);
 void set_tune_inhibit(bool);
+bool tune_inhibited();
 void set_describe(char*, int);
 bool describing();
 int gemm_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, float, float, const float*, int,
@@ -551,6 +552,11 @@ int mc_describe_conv_filter_acts(char* out, int outLen, int reluBits, int numIma
     return rc;
 }
 
+int mc_set_autotune(int enabled) {
+    set_tune_inhibit(enabled == 0);
+    return MC_OK;
+}
+
 size_t mc_relu_bits_words(int rows, int ld) { return rows > 0 && ld > 0 ? (size_t)((rows + 31) / 32) * ld : 0; }
 
 int mc_gemm_relu_bits(const float* A, const float* B, float* C, int m, int n, int k, int transA, int transB, int lda, int ldb, int ldc,
@@ -715,11 +721,12 @@ int mc_conv_weight_grad_noalloc(const float* images, const float* hidActs, float
     if (rc) return rc;
     // every slab element the reduction reads is written by the product first (chunks cover the whole (module, image) axis),
     // so nothing left in the array by an earlier call is ever read: no clearing needed
+    const bool was = tune_inhibited();
     set_tune_inhibit(true);   // the timed tile trial creates events and blocks: not from this entry point
     rc = mc_conv_weight_grad(images, hidActs, weightGrad, numImages, numImgColors, imgSizeY, imgSizeX, numFilters, filterSize,
                              paddingStart, moduleStride, numModulesY, numModulesX, numGroups, scaleTargets, scaleOutput, ws,
                              kStaticScratchBytes, s);
-    set_tune_inhibit(false);
+    set_tune_inhibit(was);
     return rc;
 }
 

@@ -289,6 +289,10 @@ __global__ void k_sum_cols4(const float4* __restrict__ v, float4* out, int rows,
     }
 }
 
+__global__ void k_accumulate_f64(double* dst, const double* __restrict__ src, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] += src[i];
+}
+
 __global__ void __launch_bounds__(RED_T) k_sum_all(const float* __restrict__ v, size_t n, double* out) {
     __shared__ double shd[RED_T];
     double acc = 0.0;
@@ -647,6 +651,12 @@ int mc_axpby(float* y, const float* x, float sy, float sx, size_t n, mcStream_t 
 int mc_scale(float* y, const float* x, float sx, size_t n, mcStream_t s) {
     MC_REQUIRE(y && x, "mc_scale: null pointer");
     return map1(x, y, n, FScale{sx}, S(s));
+}
+
+int mc_accumulate_f64(double* dst, const double* src, int n, mcStream_t s) {
+    MC_REQUIRE(dst && src && n > 0 && n <= 1024, "mc_accumulate_f64: bad arguments");
+    hipLaunchKernelGGL(k_accumulate_f64, dim3(1), dim3(64), 0, S(s), dst, src, n);
+    return launch_status("mc_accumulate_f64");
 }
 
 int mc_sum_all(const float* v, size_t n, double* out, mcStream_t s) {

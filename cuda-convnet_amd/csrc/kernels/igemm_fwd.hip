@@ -11,6 +11,7 @@ void set_describe(char* buf, int len) { g_describeBuf = buf; g_describeLen = len
 bool describing() { return g_describeBuf != nullptr; }
 // While set (per host thread), a shape that has not been tuned yet runs the static rule's tile instead of the timed trial.
 void set_tune_inhibit(bool on) { g_tuneInhibit = on; }
+bool tune_inhibited() { return g_tuneInhibit; }
 
 // =================================================================================
 // conv forward: C[f][(m,n)] ; Mg = F/groups, Ng = M*N, Kg = fc*fp

@@ -9,6 +9,7 @@
 #include <time.h>
 
 #include <algorithm>
+#include <atomic>
 #include <deque>
 #include <functional>
 #include <iostream>
@@ -26,7 +27,10 @@ std::mutex g_randMutex;
 std::deque<std::vector<float>> g_injected;
 unsigned long long g_seed = 0, g_offset = 0;
 bool g_seeded = false;
+std::atomic<unsigned long long> g_randDraws{0};   // calls that took (or injected) random numbers: a step that draws cannot be replayed
 }  // namespace
+
+unsigned long long randDraws() { return g_randDraws.load(std::memory_order_relaxed); }
 
 void setRandSeed(unsigned long long seed) {
     std::lock_guard<std::mutex> g(g_randMutex);
@@ -41,6 +45,7 @@ void injectUniform(const float* host, size_t n) {
 }
 
 void fillUniform(DevMat& m) {
+    g_randDraws.fetch_add(1, std::memory_order_relaxed);
     std::unique_lock<std::mutex> g(g_randMutex);
     if (!g_injected.empty()) {
         std::vector<float> mask;
@@ -63,6 +68,7 @@ void fillUniform(DevMat& m) {
 }
 
 bool reserveUniform(size_t n, unsigned long long* seed, unsigned long long* offset) {
+    g_randDraws.fetch_add(1, std::memory_order_relaxed);
     std::lock_guard<std::mutex> g(g_randMutex);
     if (!g_injected.empty()) return false;
     if (!g_seeded) {
@@ -281,6 +287,7 @@ ConvNet::ConvNet(PyObject* layerParams, int minibatchSize, int deviceID) : _devi
     for (Layer* l : _layers)
         for (Layer* p : l->getPrev()) p->addNext(l);
     for (Layer* l : _layers) l->postInit();
+    for (Layer* l : _layers) _conserveMem |= l->conservesMem();
     _dp = new DataProvider(minibatchSize);
 }
 
@@ -422,6 +429,7 @@ float* ConvNet::workspace(size_t bytes) {
         }
         _workspaceBytes = (bytes + (4u << 20)) / (4u << 20) * (4u << 20);
         RT_HIP(hipMalloc(reinterpret_cast<void**>(&_workspace), _workspaceBytes));
+        DeviceAllocator::get().noteForeignAllocation();
     }
     return _workspace;
 }
@@ -514,7 +522,7 @@ void ConvNet::endMinibatchCosts(int numCases) {
 
 Cost* ConvNet::collectCosts() {
     RT_HIP(hipStreamSynchronize(_stream));
-    int total = 0;
+    int total = _graphCases;
     for (int n : _slotCases) total += n;
     Cost* cost = new Cost(total);
     for (CostLayer* c : _costs) {
@@ -527,8 +535,115 @@ Cost* ConvNet::collectCosts() {
             c->finishCost(&host[(size_t)s * nv], _slotCases[s]);
             cost->add(c->getName(), c->getCoeff(), &host[(size_t)s * nv], nv);
         }
+        if (_graphCases && c->deviceSlots()) {   // minibatches that ran as replayed graphs: one running total (finishCost is additive)
+            std::vector<double> sum(nv);
+            RT_HIP(hipMemcpy(sum.data(), c->deviceSlots() + (size_t)CostLayer::GRAPH_TOTAL * nv, nv * sizeof(double), hipMemcpyDeviceToHost));
+            c->finishCost(sum.data(), _graphCases);
+            cost->add(c->getName(), c->getCoeff(), sum.data(), nv);
+        }
     }
     return cost;
+}
+
+int ConvNet::costSlotIndex() const { return _capturing ? (int)CostLayer::GRAPH_SLOT : _slot; }
+
+void ConvNet::beginBatchCosts() {
+    _slot = 0;
+    _slotCases.clear();
+    _graphCases = 0;
+    for (CostLayer* c : _costs)
+        if (c->deviceSlots())
+            RT_HIP(hipMemsetAsync(c->deviceSlots() + (size_t)CostLayer::GRAPH_TOTAL * c->numCostValues(), 0, sizeof(double) * c->numCostValues(), _stream));
+}
+
+// ------------------------------------------------------------------------------------------
+// One training step.  Small nets are bound by launches (layers-80sec: ~35 kernels of 3-30 us per step), so a step whose
+// launches are the same every time -- same minibatch shape, no random numbers, no communicator, no per-launch profiling --
+// is captured into a HIP graph the third time its shape comes up (the first two eager runs size every buffer and let the
+// contraction autotuner settle) and replayed from then on: one launch per step plus the staging copies of the minibatch.
+// Whatever differs from step to step stays outside the graph: the minibatch is staged into fixed matrices before the
+// launch, and the costs go to a fixed slot that the graph adds to a running total (read once per batch).
+// MC_NO_STEP_GRAPH=1 keeps every step eager.
+// ------------------------------------------------------------------------------------------
+bool ConvNet::stepGraphsAllowed() const {
+    static const bool off = getenv("MC_NO_STEP_GRAPH") != nullptr;
+    return !off && !_stochastic && !_comm.active() && !profileOn() && !_conserveMem;
+}
+
+void ConvNet::eagerStep(DevMatV& mb, int cases) {
+    fprop(mb, PASS_TRAIN);
+    endMinibatchCosts(cases);
+    bprop(PASS_TRAIN);
+    updateWeights();
+}
+
+bool ConvNet::captureStep(StepGraph& g, DevMatV& mb) {
+    hipGraph_t graph = nullptr;
+    bool ok = hipStreamBeginCapture(_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+        _capturing = true;
+        (void)mc_set_autotune(0);
+        try {
+            fprop(mb, PASS_TRAIN);
+            for (CostLayer* c : _costs)
+                if (c->deviceSlots())
+                    RT_MC(mc_accumulate_f64(c->deviceSlots() + (size_t)CostLayer::GRAPH_TOTAL * c->numCostValues(),
+                                            c->deviceSlots() + (size_t)CostLayer::GRAPH_SLOT * c->numCostValues(), c->numCostValues(), ST()));
+            bprop(PASS_TRAIN);
+            updateWeights();
+        } catch (std::exception& e) {
+            ok = false;
+            g.why = e.what();
+        }
+        (void)mc_set_autotune(1);
+        _capturing = false;
+        if (hipStreamEndCapture(_stream, &graph) != hipSuccess || !graph) ok = false;
+    }
+    if (ok && hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        ok = false;
+        g.exec = nullptr;
+    }
+    if (graph) (void)hipGraphDestroy(graph);
+    if (!ok) {
+        (void)hipGetLastError();   // the failed capture's sticky error is not the next launch's
+        g.bad = true;
+        if (getenv("MC_STEP_GRAPH_VERBOSE")) fprintf(stderr, "[libkernel] step graph not captured (%s): steps of this shape stay eager\n", g.why.c_str());
+    }
+    return ok;
+}
+
+void ConvNet::trainStep(int miniIdx) {
+    const int cases = _dp->getNumCasesInMinibatch(miniIdx);
+    DevMatV& mb = _dp->getMinibatch(miniIdx);   // staged into the provider's fixed matrices: same addresses every step
+    StepGraph& g = _stepGraphs[cases];
+    const unsigned long long stamp = DeviceAllocator::get().allocations();
+    if (g.exec && g.allocStamp != stamp) {   // some matrix has moved since the capture: the graph's addresses are stale
+        (void)hipGraphExecDestroy(g.exec);
+        g.exec = nullptr;
+        g.eagerRuns = 1;
+    }
+    if (stepGraphsAllowed() && !g.bad) {
+        if (!g.exec && g.eagerRuns >= 2) {
+            captureStep(g, mb);   // nothing runs during the capture
+            g.allocStamp = DeviceAllocator::get().allocations();
+            if (g.exec && g.allocStamp != stamp) {   // the step still allocates: not a shape to replay yet
+                (void)hipGraphExecDestroy(g.exec);
+                g.exec = nullptr;
+                g.eagerRuns = 1;
+            }
+        }
+        if (g.exec) {
+            RT_HIP(hipGraphLaunch(g.exec, _stream));
+            _graphCases += cases;
+            _graphReplays++;
+            for (Weights* w : _allWeights) w->markUpdated();
+            return;
+        }
+    }
+    const unsigned long long draws = randDraws();
+    eagerStep(mb, cases);
+    if (randDraws() != draws) _stochastic = true;   // dropout & co. take new random numbers every step
+    g.eagerRuns++;
 }
 
 double ConvNet::getCostValue() {
@@ -641,11 +756,11 @@ void TrainingWorker::run() {
     for (int i = 0; i < dp.getNumMinibatches(); i++) {
         // a ragged global tail is dealt out unevenly (dp.shard_columns): its gradient scale is 1 / (its true global size)
         if (_globalCases > 0) _convNet->setGlobalMinibatchCases((int)std::min(gmb, _globalCases - i * gmb));
-        _convNet->fprop(i, _test ? PASS_TEST : PASS_TRAIN);
-        _convNet->endMinibatchCosts(dp.getNumCasesInMinibatch(i));
-        if (!_test) {
-            _convNet->bprop(PASS_TRAIN);
-            _convNet->updateWeights();
+        if (_test) {
+            _convNet->fprop(i, PASS_TEST);
+            _convNet->endMinibatchCosts(dp.getNumCasesInMinibatch(i));
+        } else {
+            _convNet->trainStep(i);
         }
     }
     _convNet->setGlobalMinibatchCases(0);
@@ -660,11 +775,11 @@ void ResidentWorker::run() {
     _convNet->beginBatchCosts();
     for (int k = 0; k < _count; k++) {
         const int i = (_first + k) % nmb;
-        _convNet->fprop(i, _test ? PASS_TEST : PASS_TRAIN);
-        _convNet->endMinibatchCosts(dp.getNumCasesInMinibatch(i));
-        if (!_test) {
-            _convNet->bprop(PASS_TRAIN);
-            _convNet->updateWeights();
+        if (_test) {
+            _convNet->fprop(i, PASS_TEST);
+            _convNet->endMinibatchCosts(dp.getNumCasesInMinibatch(i));
+        } else {
+            _convNet->trainStep(i);
         }
     }
     _convNet->getResultQueue().enqueue(new WorkResult(WorkResult::BATCH_DONE, _convNet->collectCosts()));

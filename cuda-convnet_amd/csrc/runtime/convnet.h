@@ -150,8 +150,12 @@ public:
     void fprop(DevMatV& data, PASS_TYPE passType);
     void bprop(PASS_TYPE passType);
     // cost handling: slots on the device, read once per batch
-    int costSlotIndex() const { return _slot; }
-    void beginBatchCosts() { _slot = 0; _slotCases.clear(); }
+    int costSlotIndex() const;
+    void beginBatchCosts();
+    // while a step is being captured into a graph the costs go to a fixed slot (CostLayer::GRAPH_SLOT)
+    bool capturing() const { return _capturing; }
+    void trainStep(int miniIdx);   // fprop + costs + bprop + update of one minibatch, eager or as a replayed graph
+    long stepGraphReplays() const { return _graphReplays; }
     void endMinibatchCosts(int numCases);
     Cost* collectCosts();
     double getCostValue();   // synchronous, last minibatch only (grad check)
@@ -177,6 +181,21 @@ public:
     std::map<std::string, DevMat*> debugActs();   // layer name -> output matrix
 
 private:
+    struct StepGraph {
+        hipGraphExec_t exec = nullptr;
+        int eagerRuns = 0;
+        unsigned long long allocStamp = 0;   // DeviceAllocator::allocations() when captured
+        bool bad = false;      // a capture failed: steps of this shape stay eager
+        std::string why;
+    };
+    bool stepGraphsAllowed() const;
+    void eagerStep(DevMatV& mb, int cases);
+    bool captureStep(StepGraph& g, DevMatV& mb);
+    std::map<int, StepGraph> _stepGraphs;   // by cases in the minibatch
+    bool _capturing = false, _stochastic = false, _conserveMem = false;
+    int _graphCases = 0;                    // cases of this batch that ran as replayed graphs
+    long _graphReplays = 0;                 // steps replayed since initModel
+
     void run();
     void initDevice();
     Layer* initLayer(const std::string& layerType, PyObject* paramsDict);

@@ -32,6 +32,8 @@ void profileSetFilter(const char* filter) {
     g_profOn = !g_profFilter.empty();
 }
 
+bool profileOn() { return g_profOn; }
+
 void profileSetLayer(const char* layerName) {
     if (g_profOn) g_profLayer = layerName ? layerName : "";
 }
@@ -88,6 +90,7 @@ static size_t round_capacity(size_t elems) {
 }
 
 float* DeviceAllocator::alloc(size_t elems, size_t* capacityOut) {
+    _allocations++;
     const size_t cap = round_capacity(elems ? elems : 1);
     auto it = _free.lower_bound(cap);
     // reuse a cached block unless it would waste more than half of itself

@@ -40,6 +40,7 @@ private:
     int _slot = -1;
 };
 void profileSetFilter(const char* filter);            // NULL / "" switches profiling off
+bool profileOn();
 void profileSetLayer(const char* layerName);
 void profileSetPhase(const char* phase);              // "fwd" / "wgrad" / "bwd": part of the key
 void profileReport(std::map<std::string, std::pair<long, double>>& out, bool reset);
@@ -67,12 +68,17 @@ public:
     float* alloc(size_t elems, size_t* capacityOut);
     void release(float* p, size_t capacity);
     void trim();  // hipFree everything cached
+    // how many blocks have been handed out so far: a matrix that (re)allocates changes address, which invalidates
+    // anything that baked addresses in (ConvNet's captured training steps compare this stamp before every replay)
+    unsigned long long allocations() const { return _allocations; }
+    void noteForeignAllocation() { _allocations++; }   // buffers the net allocates itself
     size_t bytesInUse() const { return _inUse; }
     size_t bytesCached() const { return _cached; }
 
 private:
     std::multimap<size_t, float*> _free;  // capacity (elements) -> block
     size_t _inUse = 0, _cached = 0;
+    unsigned long long _allocations = 0;
 };
 
 class DevMat {

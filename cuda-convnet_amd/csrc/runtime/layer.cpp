@@ -973,12 +973,12 @@ CostLayer::~CostLayer() {
 
 double* CostLayer::costSlot() {
     if (!_slots) {
-        RT_HIP(hipMalloc(reinterpret_cast<void**>(&_slots), sizeof(double) * MAX_SLOTS * numCostValues()));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&_slots), sizeof(double) * (MAX_SLOTS + 2) * numCostValues()));
         // on the compute stream: a null-stream memset is not ordered against a non-blocking stream
-        RT_HIP(hipMemsetAsync(_slots, 0, sizeof(double) * MAX_SLOTS * numCostValues(), computeStream()));
+        RT_HIP(hipMemsetAsync(_slots, 0, sizeof(double) * (MAX_SLOTS + 2) * numCostValues(), computeStream()));
     }
     const int s = _convNet->costSlotIndex();
-    if (s >= MAX_SLOTS) throw std::runtime_error(fmt("more than %d minibatches in one batch", MAX_SLOTS));
+    if (s >= MAX_SLOTS && !_convNet->capturing()) throw std::runtime_error(fmt("more than %d minibatches in one batch", MAX_SLOTS));
     return _slots + (size_t)s * numCostValues();
 }
 

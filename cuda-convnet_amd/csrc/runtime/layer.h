@@ -145,6 +145,7 @@ public:
     virtual DevMat& getActs();
     virtual DevMat& getActsGrad();
     int getNumOutputs() const { return _numOutputs; }
+    bool conservesMem() const { return _conserveMem; }
     virtual void postInit();
     bool isGradConsumer();
     virtual bool isGradProducer() { return true; }
@@ -492,6 +493,9 @@ public:
     double* costSlot();          // device address of this minibatch's values
     static CostLayer& makeCostLayer(ConvNet* convNet, const std::string& type, PyObject* paramsDict);
     static const int MAX_SLOTS = 4096;
+    // two more slots for minibatches that run as a captured graph (ConvNet::trainStep): the slot such a step writes, and
+    // the running total the graph adds it to.  finishCost must therefore be additive over minibatches (all of them are).
+    static const int GRAPH_SLOT = MAX_SLOTS, GRAPH_TOTAL = MAX_SLOTS + 1;
     double* deviceSlots() const { return _slots; }
 
 protected:
@@ -533,6 +537,7 @@ void fillUniform(DevMat& m);
 // generate the uniforms themselves (mc_dropout_counter).  False when an injected mask is pending: the caller
 // must then take the fillUniform path, which consumes it.
 bool reserveUniform(size_t n, unsigned long long* seed, unsigned long long* offset);
+unsigned long long randDraws();   // how many times fillUniform / reserveUniform have been called
 void injectUniform(const float* host, size_t n);
 void setRandSeed(unsigned long long seed);
 

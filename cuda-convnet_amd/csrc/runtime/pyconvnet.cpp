@@ -326,6 +326,7 @@ static PyObject* setProfile(PyObject*, PyObject* args) {
 }
 
 // getProfile() -> {key: (launches, total_ms)}; clears the records.  With a data-parallel communicator it also carries the
+// "net/step_graph:replays" -> (training steps replayed as captured graphs since initModel, 0) and the
 // counters since the last call: "dp/allreduce:bytes" -> (all-reduce calls, bytes reduced), "dp/wait:ms" -> (steps,
 // milliseconds the compute stream was blocked waiting for the reductions, i.e. what back-propagation did not hide).
 static PyObject* getProfile(PyObject*, PyObject*) {
@@ -333,6 +334,7 @@ static PyObject* getProfile(PyObject*, PyObject*) {
     std::map<std::string, std::pair<long, double>> rep;
     PyObject* ok = run_on_device([&] {
         profileReport(rep, true);
+        rep["net/step_graph:replays"] = std::make_pair(model->stepGraphReplays(), 0.0);   // training steps replayed as HIP graphs so far
         if (model->comm().active()) {
             const GradComm::Stats st = model->comm().takeStats();
             rep["dp/allreduce:bytes"] = std::make_pair(st.calls, st.bytes);

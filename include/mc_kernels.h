@@ -390,6 +390,14 @@ int mc_axpby(float* y, const float* x, float scaleY, float scaleX, size_t n, mcS
 int mc_scale(float* y, const float* x, float scaleX, size_t n, mcStream_t stream);
 /* out[0] = sum of v[0..n) accumulated in double, fixed order (cost read-back). */
 int mc_sum_all(const float* v, size_t n, double* out, mcStream_t stream);
+/* dst[i] += src[i], i < n, in double: accumulates a minibatch's cost sums into a running total on the device.  No counterpart
+ * in the reference (its costs go to the host every minibatch, Kernel/src/convnet/cost.cu); used by the runtime's captured
+ * training step, whose kernels must write to fixed addresses. */
+int mc_accumulate_f64(double* dst, const double* src, int n, mcStream_t stream);
+/* The contraction entry points time their candidate tiles the first time they see a shape (events + a blocking wait).
+ * mc_set_autotune(0) switches that off for the calling thread (a shape not tuned yet runs the static rule's tile: same bits),
+ * mc_set_autotune(1) back on: for callers that are capturing a HIP graph or otherwise must not block.  Returns MC_OK. */
+int mc_set_autotune(int enabled);
 
 /* ---------------- softmax / logistic regression cost ----------------
  * SoftmaxLayer::fpropActs (Kernel/src/layers/layer.cu:612-622, five NVMatrix ops there),

@@ -17,12 +17,12 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def run_child(**kw):
+def run_child(_env=None, **kw):
     out = os.path.join(tempfile.mkdtemp(prefix="rt_"), "res.npz")
     cmd = [sys.executable, "-u", os.path.join(HERE, "run_net_step.py"), "--out", out]
     for k, v in kw.items():
         cmd += ["--" + k.replace("_", "-"), str(v)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, **(_env or {})))
     assert r.returncode == 0, "child failed:\n" + r.stdout[-3000:] + "\n" + r.stderr[-3000:]
     return dict(np.load(out)), r.stdout
 
@@ -132,6 +132,27 @@ def test_train_step_matches_oracle(case):
             bad.append(row)
     assert not bad, bad
     print("worst weight rel err", worst)
+
+
+@pytest.mark.parametrize("net_name,cases,mini", [("80sec", 6 * 32 + 7, 32), ("example-small", 5 * 16 + 3, 16), ("conv-local", 5 * 16, 16)])
+def test_captured_steps_equal_eager_steps(net_name, cases, mini):
+    """Nets without random layers replay their training step as a HIP graph from the third minibatch of a shape on
+    (ConvNet::trainStep).  Same kernels, same arguments: weights, increments and biases after the batch are bit-identical to
+    an all-eager run (MC_NO_STEP_GRAPH=1), the costs agree (device-side double accumulation vs host-side), and the ragged tail
+    -- a shape seen once -- runs eagerly in both.  Also against the oracle, like every other whole-step test."""
+    got, _ = run_child(net=net_name, cases=cases, mini=mini, init_w=0.05)
+    ref, _ = run_child(net=net_name, cases=cases, mini=mini, init_w=0.05, _env={"MC_NO_STEP_GRAPH": "1"})
+    full = cases // mini
+    assert int(got["graphReplays"]) == full - 2 and int(ref["graphReplays"]) == 0
+    assert int(got["numCases"]) == int(ref["numCases"]) == cases
+    for k in ref:
+        if k.startswith("cost:"):
+            np.testing.assert_allclose(got[k], ref[k], rtol=1e-12, atol=1e-9)
+        elif k[0] in "WB":
+            assert np.array_equal(got[k], ref[k]), k
+    net, layers, costs = oracle_run(net_name, cases, mini, init_w=0.05)
+    for k, v in costs.items():
+        np.testing.assert_allclose(got["cost:" + k][0], v[0], rtol=2e-4, atol=1e-3)
 
 
 def test_test_pass_costs_and_no_update():

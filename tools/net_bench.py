@@ -18,6 +18,6 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 libkernel.startResident(0, 0, steps); costs, n = libkernel.finishBatch()
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 libkernel.setProfile("*"); libkernel.startResident(0, 0, 5); libkernel.finishBatch(); tab = libkernel.getProfile(); libkernel.setProfile("")
-rows = sorted(((k, c / 5.0, ms / c) for k, (c, ms) in tab.items()), key=lambda r: -r[1] * r[2])
+rows = sorted(((k, c / 5.0, ms / c) for k, (c, ms) in tab.items() if c and ms), key=lambda r: -r[1] * r[2])
 print("%s mb=%d: %.0f images/s, %.3f ms/step, cost/case %.4f; kernel time/step %.3f ms" % (net, mb, mb * steps / dt, dt / steps * 1e3, list(costs.values())[0][0] / n, sum(r[1] * r[2] for r in rows)))
 for k, c, ms in rows[:10]: print("   %-52s x%.0f %8.4f ms" % (k, c, ms))
