@@ -68,6 +68,9 @@ constexpr int THREADS = 256;
 #endif
 #ifndef MC_BK_KC
 #define MC_BK_KC 32   // k extent of one LDS tile when both operands are k-contiguous (weight gradients)
+// (measured, tools/build_variant.sh bk64 -DMC_BK_KC=64: 256-byte instead of 128-byte runs per row and K step do not help --
+// NIN cccp1 weight gradient 117 -> 151 us, cccp2 70 -> 90, cccp3 40 -> 56: twice the fragment registers and LDS per tile cost
+// more than the longer DRAM bursts gain)
 #endif
 #ifndef MC_BK
 #define MC_BK 16   // k extent of one LDS tile for the contractions whose operands are not both k-contiguous
@@ -987,11 +990,22 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
 enum { T11, T21, T31, T51, T23, T32, T14, T24, NTILES, T33K = NTILES };   // NTILES: the tiles the autotuner may pick among
 static const char* const kTileName[NTILES + 1] = {"32x128", "64x128", "96x128", "160x128", "128x192", "192x128", "128x32", "128x64", "96x192k2"};
 
+// LDS footprint of a tile (three stages + the bias column): a k-contiguous build with a longer K tile (MC_BK_KC=64) keeps
+// only the tiles that still fit 160 KB; launch_tile maps the others to the nearest one that does.
+template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC>
+constexpr bool tile_fits() {
+    return (3 * (size_t)(Loader<AADDR, 32 * MT * WM, BK, VEC>::LDS_FLOATS + Loader<BADDR, 32 * NT * WN, BK, VEC>::LDS_FLOATS) + 32 * MT * WM) * sizeof(float) <= 160 * 1024;
+}
+
 template <class AADDR, class BADDR, int BK, int VEC, int EPI>
 int launch_tile(int tile, const typename AADDR::P& pa, const typename BADDR::P& pb, const ConvG& cg, const Dims& d, const Epi& ep,
                 int chunks, hipStream_t st) {
     // the slow epilogue exists for three row heights only (any tile is correct for any shape): fewer instantiations
     if constexpr (EPI == EPI_SLOW) tile = tile == T51 || tile == T32 ? T31 : tile == T23 ? T21 : tile;
+    if constexpr (!tile_fits<AADDR, BADDR, 3, 1, 1, 4, BK, VEC>()) tile = tile == T31 ? T21 : tile;
+    if constexpr (!tile_fits<AADDR, BADDR, 5, 1, 1, 4, BK, VEC>()) tile = tile == T51 ? T21 : tile;
+    if constexpr (!tile_fits<AADDR, BADDR, 2, 3, 2, 2, BK, VEC>()) tile = tile == T23 ? T21 : tile;
+    if constexpr (!tile_fits<AADDR, BADDR, 3, 2, 2, 2, BK, VEC>()) tile = tile == T32 ? T21 : tile;
     switch (tile) {
         case T11: return launch_cfg<AADDR, BADDR, 1, 1, 1, 4, BK, VEC, EPI>(pa, pb, cg, d, ep, chunks, st);
         case T21: return launch_cfg<AADDR, BADDR, 2, 1, 1, 4, BK, VEC, EPI>(pa, pb, cg, d, ep, chunks, st);
@@ -1007,13 +1021,20 @@ int launch_tile(int tile, const typename AADDR::P& pa, const typename BADDR::P& 
 #endif
     if constexpr (EPI != EPI_SLOW) {
         switch (tile) {
-            case T51: return launch_cfg<AADDR, BADDR, 5, 1, 1, 4, BK, VEC, EPI>(pa, pb, cg, d, ep, chunks, st);
-            case T23: return launch_cfg<AADDR, BADDR, 2, 3, 2, 2, BK, VEC, EPI>(pa, pb, cg, d, ep, chunks, st);
-            case T32: return launch_cfg<AADDR, BADDR, 3, 2, 2, 2, BK, VEC, EPI>(pa, pb, cg, d, ep, chunks, st);
+            case T51:
+                if constexpr (tile_fits<AADDR, BADDR, 5, 1, 1, 4, BK, VEC>()) return launch_cfg<AADDR, BADDR, 5, 1, 1, 4, BK, VEC, EPI>(pa, pb, cg, d, ep, chunks, st);
+                break;
+            case T23:
+                if constexpr (tile_fits<AADDR, BADDR, 2, 3, 2, 2, BK, VEC>()) return launch_cfg<AADDR, BADDR, 2, 3, 2, 2, BK, VEC, EPI>(pa, pb, cg, d, ep, chunks, st);
+                break;
+            case T32:
+                if constexpr (tile_fits<AADDR, BADDR, 3, 2, 2, 2, BK, VEC>()) return launch_cfg<AADDR, BADDR, 3, 2, 2, 2, BK, VEC, EPI>(pa, pb, cg, d, ep, chunks, st);
+                break;
             default: break;
         }
     }
-    return launch_cfg<AADDR, BADDR, 3, 1, 1, 4, BK, VEC, EPI>(pa, pb, cg, d, ep, chunks, st);
+    if constexpr (tile_fits<AADDR, BADDR, 3, 1, 1, 4, BK, VEC>()) return launch_cfg<AADDR, BADDR, 3, 1, 1, 4, BK, VEC, EPI>(pa, pb, cg, d, ep, chunks, st);
+    return launch_cfg<AADDR, BADDR, 2, 1, 1, 4, BK, VEC, EPI>(pa, pb, cg, d, ep, chunks, st);
 }
 
 // Static rule (measured on MI355X, tools/tile_sweep.py over the NIN shapes): 128-column tiles (one 32-column

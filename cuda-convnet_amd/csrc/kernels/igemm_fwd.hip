@@ -49,6 +49,8 @@ int conv_filter_acts_impl(const float* images, const float* filters, float* targ
 // weight gradients.  A pure function of the shape and the CU count.  Returns the chunk count (1 = no split).
 int conv_split_plan(int rows, long cols, int K, int groups, int* kChunkOut) {
     const long tiles = (long)ceil_div(rows, 96) * ceil_div(cols, 128) * groups;
+    // (measured and dropped: aiming at 2-4 workgroups per CU for products with <= 64 rows -- layers-80sec conv2 forward, 256 tiles
+    // -- by splitting further: no faster, the extra reduction eats what the split gains)
     long chunks = num_cus() / tiles;
     *kChunkOut = 0;
     if (chunks < 2 || K < 512) return 1;

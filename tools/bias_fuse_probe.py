@@ -4,6 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cuda-convnet_amd"))
 import torch
 import mckernels as m
+if os.environ.get("MC_KERNELS_LIB"): m._LIB_PATH = os.path.abspath(os.environ["MC_KERNELS_LIB"])
 
 def ptr(t): return t.data_ptr()
 dev = "cuda"
