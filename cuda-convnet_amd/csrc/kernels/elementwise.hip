@@ -439,6 +439,64 @@ __global__ void __launch_bounds__(RED_T) k_logreg_cost_sums(const float* __restr
         sums[1] = shc[0];
     }
 }
+// The tail of a classifier in one launch: k_softmax, k_logreg_cost_sums and (optionally) k_logreg_softmax_grad for the same
+// cases, each formula exactly as in those kernels, so every output equals theirs bit for bit.  One workgroup: lane t takes
+// cases t, t + RED_T, ... (three dependent launches of a few microseconds each are all latency).
+__global__ void __launch_bounds__(RED_T) k_softmax_logreg(const float* __restrict__ labels, const float* __restrict__ in, float* probs,
+                                                          float* labelLogProbs, float* correctProbs, double* sums, float* grad, bool add,
+                                                          float coeff, int numCases, int numOut) {
+    __shared__ double shl[RED_T], shc[RED_T];
+    double accL = 0.0, accC = 0.0;
+    for (int n = threadIdx.x; n < numCases; n += RED_T) {
+        float mx = in[n];
+        for (int j = 1; j < numOut; ++j) mx = fmaxf(mx, in[(size_t)j * numCases + n]);
+        float sum = 0.f;
+        for (int j = 0; j < numOut; ++j) {
+            const float e = expf(in[(size_t)j * numCases + n] - mx);
+            probs[(size_t)j * numCases + n] = e;
+            sum += e;
+        }
+        float maxp = 0.f;
+        for (int j = 0; j < numOut; ++j) {
+            const float p = probs[(size_t)j * numCases + n] / sum;
+            probs[(size_t)j * numCases + n] = p;
+            maxp = j == 0 ? p : fmaxf(maxp, p);
+        }
+        const int label = (int)labels[n];
+        const float lp = probs[(size_t)label * numCases + n];
+        const float ll = logf(lp);
+        float cp = 0.f;
+        if (lp == maxp) {
+            int numMax = 0;
+            for (int j = 0; j < numOut; ++j) numMax += probs[(size_t)j * numCases + n] == maxp;
+            cp = 1.0f / (float)numMax;
+        }
+        labelLogProbs[n] = ll;
+        correctProbs[n] = cp;
+        accL += (double)ll;
+        accC += (double)cp;
+        if (grad)
+            for (int j = 0; j < numOut; ++j) {
+                const size_t idx = (size_t)j * numCases + n;
+                const float v = coeff * ((label == j) - probs[idx]);
+                grad[idx] = add ? grad[idx] + v : v;
+            }
+    }
+    shl[threadIdx.x] = accL;
+    shc[threadIdx.x] = accC;
+    __syncthreads();
+    for (int s = RED_T / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            shl[threadIdx.x] += shl[threadIdx.x + s];
+            shc[threadIdx.x] += shc[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sums[0] = shl[0];
+        sums[1] = shc[0];
+    }
+}
 // kLogregCostGrad (layer_kernels.cu:84-101): dE/dy_j = coeff * (label == j) / y_j
 __global__ void k_logreg_grad(const float* __restrict__ labels, const float* __restrict__ probs, float* target, bool add,
                               float coeff, int numCases, int numOut) {
@@ -702,6 +760,15 @@ int mc_compute_logreg_cost_sums(const float* labels, const float* probs, float* 
     MC_REQUIRE(labels && probs && labelLogProbs && correctProbs && sums && numCases > 0 && numOut > 0, "mc_compute_logreg_cost_sums: bad arguments");
     hipLaunchKernelGGL(k_logreg_cost_sums, dim3(1), dim3(RED_T), 0, S(s), labels, probs, labelLogProbs, correctProbs, sums, numCases, numOut);
     return launch_status("mc_compute_logreg_cost_sums");
+}
+
+int mc_softmax_logreg(const float* labels, const float* input, float* probs, float* labelLogProbs, float* correctProbs, double* sums,
+                      float* gradTarget, int add, float coeff, int numCases, int numOut, mcStream_t s) {
+    MC_REQUIRE(labels && input && probs && labelLogProbs && correctProbs && sums && numCases > 0 && numOut > 0, "mc_softmax_logreg: bad arguments");
+    MC_REQUIRE(probs != input, "mc_softmax_logreg: probs must not alias the input");
+    hipLaunchKernelGGL(k_softmax_logreg, dim3(1), dim3(RED_T), 0, S(s), labels, input, probs, labelLogProbs, correctProbs, sums, gradTarget,
+                       add != 0, coeff, numCases, numOut);
+    return launch_status("mc_softmax_logreg");
 }
 
 int mc_compute_logreg_grad(const float* labels, const float* probs, float* target, int add, float coeff, int numCases,

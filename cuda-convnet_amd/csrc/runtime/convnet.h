@@ -163,6 +163,7 @@ public:
     bool checkGradient(const std::string& name, float eps, Weights& weights);
 
     // plumbing for layers
+    DevMat* currentData(int dataIdx) { return _data && dataIdx >= 0 && dataIdx < (int)_data->size() ? (*_data)[dataIdx] : nullptr; }   // this pass's input matrices
     void registerWeights(Weights* w) { _allWeights.push_back(w); }
     void gradientReady(Weights& w);           // called from WeightLayer::bpropCommon
     float* workspace(size_t bytes);

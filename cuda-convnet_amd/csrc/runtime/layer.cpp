@@ -708,11 +708,39 @@ void LocalUnsharedLayer::bpropActs(DevMat& v, int i, float scaleTargets, PASS_TY
 // ==========================================================================================
 // Softmax / eltsum / data                                                 (layer.cu:609-705)
 // ==========================================================================================
-void SoftmaxLayer::fpropActs(int, float, PASS_TYPE) {
+void SoftmaxLayer::fpropActs(int, float, PASS_TYPE passType) {
+    // A small classifier tail (softmax -> logreg cost, labels straight from the data) is three dependent launches of a few
+    // microseconds each: one launch computes the probabilities, the cost's outputs and sums and, when training, the gradient
+    // coeff * (1[label] - p) into the layer below (same values as the separate kernels, bit for bit).  MC_NO_FUSED_TAIL=1: off.
+    static const bool off = getenv("MC_NO_FUSED_TAIL") != nullptr;
+    _gradDone = false;
+    LogregCostLayer* cost = _next.size() == 1 ? dynamic_cast<LogregCostLayer*>(_next[0]) : nullptr;
+    if (cost && !off && (passType == PASS_TRAIN || passType == PASS_TEST) && (long)numCases() * _numOutputs <= 32768 && cost->getPrev().size() == 2 &&
+        cost->getPrev()[1] == this) {
+        DataLayer* lab = dynamic_cast<DataLayer*>(cost->getPrev()[0]);
+        DevMat* labels = lab ? _convNet->currentData(lab->dataIdx()) : nullptr;
+        if (labels && labels->rows() == 1 && labels->cols() == numCases()) {
+            float* grad = nullptr;
+            Layer* below = _prev[0];
+            if (passType == PASS_TRAIN && cost->getCoeff() != 0 && below->isGradConsumer() && below->getNext().size() == 1 && !_conserveMem &&
+                !below->conservesMem()) {
+                DevMat& tgt = below->getActsGrad();   // written now, read when back-propagation reaches `below`; nothing else touches it in between
+                tgt.resize(below->getNumOutputs(), numCases());
+                grad = tgt.data();
+                _gradDone = true;
+            }
+            cost->fusedTail(labels->data(), _inputs[0]->data(), getActs().data(), grad, numCases(), _numOutputs);
+            return;
+        }
+    }
     RT_MC(mc_softmax(_inputs[0]->data(), getActs().data(), numCases(), _numOutputs, ST()));
 }
 
 void SoftmaxLayer::bpropActs(DevMat& v, int, float scaleTargets, PASS_TYPE) {
+    if (_gradDone) {   // the fused tail wrote this gradient during fprop (scaleTargets is 0: this layer is `below`'s only consumer)
+        _gradDone = false;
+        return;
+    }
     // directly under a logreg cost the fused gradient coeff*(1[label] - p) is used (layer.cu:626-631)
     const bool doLogregGrad = _next.size() == 1 && _next[0]->getType() == "cost.logreg";
     DevMat& tgt = _prev[0]->getActsGrad();
@@ -998,8 +1026,19 @@ CostLayer& CostLayer::makeCostLayer(ConvNet* convNet, const std::string& type, P
     throw std::runtime_error("Unknown cost layer type " + type);
 }
 
+void LogregCostLayer::fusedTail(const float* labels, const float* in, float* probs, float* grad, int N, int numOut) {
+    _ownOutputs.resize(1, N);
+    _correctProbs.resize(1, N);
+    RT_MC(mc_softmax_logreg(labels, in, probs, _ownOutputs.data(), _correctProbs.data(), costSlot(), grad, 0, _coeff, N, numOut, ST()));
+    _fusedThisPass = true;
+}
+
 void LogregCostLayer::fpropActs(int inpIdx, float, PASS_TYPE) {
     if (inpIdx != 0) return;   // both inputs are used together
+    if (_fusedThisPass) {      // the softmax layer below has already produced everything (fusedTail)
+        _fusedThisPass = false;
+        return;
+    }
     DevMat& labels = *_inputs[0];
     DevMat& probs = *_inputs[1];
     const int N = labels.cols();

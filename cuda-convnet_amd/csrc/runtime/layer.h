@@ -322,6 +322,7 @@ public:
 protected:
     void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
     void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    bool _gradDone = false;   // this pass's gradient was written by the fused classifier tail (mc_softmax_logreg) during fprop
 };
 
 class EltwiseSumLayer : public Layer {
@@ -406,6 +407,7 @@ public:
     void fprop(PASS_TYPE passType) override;
     void fprop(DevMatV& data, PASS_TYPE passType) override;
     bool isGradProducer() override { return false; }
+    int dataIdx() const { return _dataIdx; }
 
 protected:
     void fpropActs(int, float, PASS_TYPE) override {}
@@ -508,11 +510,15 @@ public:
     LogregCostLayer(ConvNet* convNet, PyObject* paramsDict) : CostLayer(convNet, paramsDict) {}
     int numCostValues() const override { return 2; }
     void finishCost(double* vals, int numCases) const override;
+    // The softmax layer below runs softmax + this cost (+ the gradient into `grad`, nullable) as one launch and tells the
+    // cost so: its own fpropActs then has nothing left to do this pass.
+    void fusedTail(const float* labels, const float* in, float* probs, float* grad, int numCases, int numOut);
 
 protected:
     void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
     void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
     DevMat _correctProbs;
+    bool _fusedThisPass = false;
 };
 
 class SumOfSquaresCostLayer : public CostLayer {

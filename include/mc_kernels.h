@@ -413,6 +413,15 @@ int mc_compute_logreg_cost(const float* labels, const float* probs, float* label
 int mc_compute_logreg_cost_sums(const float* labels, const float* probs, float* labelLogProbs,
                                 float* correctProbs, double* sums, int numCases, int numOut,
                                 mcStream_t stream);
+/* SoftmaxLayer::fpropActs + LogregCostLayer::fpropActs + SoftmaxLayer::bpropActs under a logreg cost (layer.cu:617-631,
+ * 993-1005; kernels layer_kernels.cu:41-74, 137-152) for one minibatch in ONE launch: probs = softmax(input),
+ * labelLogProbs / correctProbs / sums as mc_compute_logreg_cost_sums, and -- when gradTarget is not NULL --
+ * gradTarget = (add ? gradTarget : 0) + coeff * (1[label] - probs), the gradient with respect to `input`.  Every output is
+ * bit-identical to mc_softmax, mc_compute_logreg_cost_sums and mc_compute_logreg_softmax_grad run one after the other; meant
+ * for classifier tails of up to a few thousand (class, case) pairs, where three dependent launches are pure latency. */
+int mc_softmax_logreg(const float* labels, const float* input, float* probs, float* labelLogProbs,
+                      float* correctProbs, double* sums, float* gradTarget, int add, float coeff,
+                      int numCases, int numOut, mcStream_t stream);
 int mc_compute_logreg_grad(const float* labels, const float* probs, float* target, int add,
                            float coeff, int numCases, int numOut, mcStream_t stream);
 int mc_compute_softmax_grad(const float* acts, const float* actsGrad, float* target, int add,

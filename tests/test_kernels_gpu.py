@@ -365,6 +365,21 @@ def test_softmax_logreg(N, K):
     g3 = nans(K, N)
     m.call("mc_compute_softmax_grad", ptr(p), ptr(g2), ptr(g3), 0, N, K, None)
     np.testing.assert_allclose(host(g3), G.softmax_grad(hp, host(g2)), rtol=1e-4, atol=1e-5)
+    # the whole classifier tail in one launch (mc_softmax_logreg): every output equals the separate kernels' bit for bit,
+    # with and without the gradient, overwriting and accumulating
+    pf, lpf, cpf, gf = nans(K, N), nans(N), nans(N), nans(K, N)
+    sf = torch.full((2,), float("nan"), dtype=torch.float64, device="cuda")
+    m.call("mc_softmax_logreg", ptr(dl), ptr(dx), ptr(pf), ptr(lpf), ptr(cpf), sf.data_ptr(), ptr(gf), 0, 0.1, N, K, None)
+    assert np.array_equal(host(pf), hp) and np.array_equal(host(lpf), host(lp)) and np.array_equal(host(cpf), host(cp))
+    assert np.array_equal(host(sf), host(sums)) and np.array_equal(host(gf), host(g))
+    base = rng.standard_normal((K, N)).astype(np.float32)
+    ga, gb = dev(base), dev(base)
+    m.call("mc_softmax_logreg", ptr(dl), ptr(dx), ptr(pf), ptr(lpf), ptr(cpf), sf.data_ptr(), ptr(ga), 1, 0.1, N, K, None)
+    m.call("mc_compute_logreg_softmax_grad", ptr(dl), ptr(p), ptr(gb), 1, 0.1, N, K, None)
+    assert np.array_equal(host(ga), host(gb))
+    pf2 = nans(K, N)
+    m.call("mc_softmax_logreg", ptr(dl), ptr(dx), ptr(pf2), ptr(lpf), ptr(cpf), sf.data_ptr(), None, 0, 0.1, N, K, None)
+    assert np.array_equal(host(pf2), hp) and np.array_equal(host(sf), host(sums))
 
 
 def test_weights_update():
