@@ -96,6 +96,7 @@ struct Dims {
     int colTiles;     // column tiles of the product (set by launch_cfg); gridDim.x = column workers <= colTiles
     int batches;      // independent products sharing one launch (unshared layers: one per module / pixel); >= 1
     int colB;         // column offset of batch b in the B operand and in C: b * colB
+    int ktabN;        // entries of the B loader's k table in LDS (set by launch_cfg; 0 = the loader decodes k arithmetically)
 };
 
 struct Epi {
@@ -180,6 +181,11 @@ struct MatKcSumAddr : MatKcAddr {
     static constexpr bool SUM = true;
 };
 template <class T, class = void>
+struct has_ktab : std::false_type {};
+template <class T>
+struct has_ktab<T, std::void_t<decltype(T::KTAB)>> : std::true_type {};
+constexpr int KTAB_MAX = 4096;   // k extents up to this are tabulated (32 KB of LDS); longer ones keep the arithmetic decode
+template <class T, class = void>
 struct has_sum : std::false_type {};
 template <class T>
 struct has_sum<T, std::void_t<decltype(T::SUM)>> : std::true_type {};
@@ -205,10 +211,36 @@ __device__ __forceinline__ bool patch_addr(const ConvG& cg, int g, int kc, int m
 }
 
 // forward B operand: k = filter tap, x = column (m*N + n); NAT (n contiguous)
+// K tables.  The gather address of these operands separates into a column part and a k part,
+//   offset(k, x) = col(x).base + entry(k).x,   valid iff (unsigned)(col.cy + dy) < limY and (unsigned)(col.cx + dx) < limX
+// with (dy, dx) packed in entry(k).y.  The column part is loop invariant in the K loop; the k part -- two float-reciprocal
+// divisions, three multiplies per element when done arithmetically, ~30 instructions per 16-byte load, which is what bounds
+// the producer waves of products with few rows (MC_STAMP: 820 of the 1100 cycles of a K step of layers-80sec conv2) -- is
+// tabulated in LDS once per workgroup (8 bytes per k) and costs one ds_read_b64.
+struct KCol { int base, cy, cx; };   // a column outside the operand gets cy = KCOL_DEAD: its range check fails for every k
+constexpr int KCOL_DEAD = -(1 << 30);
 struct PatchNatAddr {
     static const char* tag() { return "PatchNatAddr"; }
     typedef ConvP P;
     static constexpr bool KC = false;
+    static constexpr bool KTAB = true;
+    __device__ static __forceinline__ int2 ktab_entry(const ConvG& cg, int k) {
+        const int c = fdiv(k, cg.inv_fp), p = k - c * cg.fp;
+        const int fy = fdiv(p, cg.inv_fs), fx = p - fy * cg.fs;
+        return make_int2(((c * cg.H + fy) * cg.W + fx) * cg.N, (fy & 0xFFFF) | (fx << 16));
+    }
+    __device__ static __forceinline__ KCol ktab_col(const P& p, const ConvG& cg, int g, int x) {
+        const int m = x / cg.N, n = x - m * cg.N;
+        const int my = fdiv(m, cg.inv_MX), mx = m - my * cg.MX;
+        KCol c;
+        c.cy = cg.pad + my * cg.stride;
+        c.cx = cg.pad + mx * cg.stride;
+        c.base = ((g * cg.fc * cg.H + c.cy) * cg.W + c.cx) * cg.N + n;
+        if (x >= p.R) c.cy = KCOL_DEAD;
+        return c;
+    }
+    __device__ static __forceinline__ int ktab_limY(const ConvG& cg) { return cg.H; }
+    __device__ static __forceinline__ int ktab_limX(const ConvG& cg) { return cg.W; }
     __device__ static __forceinline__ bool addr(const P& p, const ConvG& cg, int g, int b, int k, int x, int& off) {
         const int m = x / cg.N;  // column decode is loop invariant in the K loop: exact integer division
         const int n = x - m * cg.N;
@@ -287,6 +319,24 @@ struct HidNatS1Addr {
     static const char* tag() { return "HidNatS1Addr"; }
     typedef ConvP P;
     static constexpr bool KC = false;
+    static constexpr bool KTAB = true;   // (see PatchNatAddr)
+    __device__ static __forceinline__ int2 ktab_entry(const ConvG& cg, int k) {
+        const int fpix = fdiv(k, cg.inv_fpg), fl = k - fpix * cg.fpg;
+        const int fy = fdiv(fpix, cg.inv_fs), fx = fpix - fy * cg.fs;
+        return make_int2((fl * cg.M - fy * cg.MX - fx) * cg.N, (int)(((unsigned)(-fy) & 0xFFFFu) | ((unsigned)(-fx) << 16)));
+    }
+    __device__ static __forceinline__ KCol ktab_col(const P& p, const ConvG& cg, int g, int x) {
+        const int px = x / cg.N, n = x - px * cg.N;
+        const int y = px / cg.W, xx = px - y * cg.W;
+        KCol c;
+        c.cy = y - cg.pad;
+        c.cx = xx - cg.pad;
+        c.base = (g * cg.fpg * cg.M + c.cy * cg.MX + c.cx) * cg.N + n;
+        if (x >= p.R) c.cy = KCOL_DEAD;
+        return c;
+    }
+    __device__ static __forceinline__ int ktab_limY(const ConvG& cg) { return cg.MY; }
+    __device__ static __forceinline__ int ktab_limX(const ConvG& cg) { return cg.MX; }
     __device__ static __forceinline__ bool addr(const P& p, const ConvG& cg, int g, int b, int k, int x, int& off) {
         const int px = x / cg.N;  // loop invariant in the K loop
         const int n = x - px * cg.N;
@@ -371,11 +421,59 @@ struct Loader {
         }
     }
 
+    // K-table loaders, vector path: the column part of every chunk this thread gathers, decoded once per tile (two integer
+    // divisions each -- left inside fetch() the compiler re-ran them every K step)
+    __device__ static __forceinline__ void prep_cols(KCol* cols, const P& p, const ConvG& cg, int g, int x0, int xlim, int tid) {
+        if constexpr (has_ktab<ADDR>::value) {
+#pragma unroll
+            for (int it = 0; it < NCH; ++it) {
+                const int c = tid + it * THREADS;
+                int dk, dx;
+                chunk_pos(c, dk, dx);
+                const int x = x0 + dx;
+                KCol col = ADDR::ktab_col(p, cg, g, x);
+                if (!((x < xlim) & (CHUNKS % THREADS == 0 || c < CHUNKS))) col.cy = KCOL_DEAD;
+                cols[it] = col;
+            }
+        }
+    }
+
     __device__ __forceinline__ void fetch(__amdgpu_buffer_rsrc_t rs, const P& p, const ConvG& cg, int g, int b, int k0, int kend,
-                                          int x0, int xlim, int tid) {
+                                          int x0, int xlim, int tid, const int2* ktab = nullptr, const KCol* cols = nullptr) {
 #ifdef MC_ABL_NOFETCH   // timing-only ablation builds (tools/build_variant.sh); wrong results
         if (k0 > 0) return;
 #endif
+        if constexpr (has_ktab<ADDR>::value) {
+            if (ktab) {   // workgroup-uniform: the k part of the address comes from the table (see KCol)
+                const unsigned limY = (unsigned)ADDR::ktab_limY(cg), limX = (unsigned)ADDR::ktab_limX(cg);
+#pragma unroll
+                for (int it = 0; it < NCH; ++it) {
+                    const int c = tid + it * THREADS;
+                    int dk, dx;
+                    chunk_pos(c, dk, dx);
+                    const int k = k0 + dk;
+                    const int2 e = ktab[k];   // the table is padded to a whole K tile
+                    const int dy = (int)(short)(e.y & 0xFFFF), dxx = e.y >> 16;
+                    if (VEC == 4) {   // the column part was decoded once per tile (prep_cols)
+                        const bool ok = ((unsigned)(cols[it].cy + dy) < limY) & ((unsigned)(cols[it].cx + dxx) < limX) & (k < kend);
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)(cols[it].base + e.x) * 4u : OOB, 0, 0);
+                        r[it] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+                    } else {
+                        const bool live = CHUNKS % THREADS == 0 || c < CHUNKS;
+                        const int x = x0 + dx;
+                        float ev[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const KCol col = ADDR::ktab_col(p, cg, g, x + u);
+                            const bool ok = ((unsigned)(col.cy + dy) < limY) & ((unsigned)(col.cx + dxx) < limX) & (k < kend) & (x + u < xlim) & live;
+                            ev[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, ok ? (unsigned)(col.base + e.x) * 4u : OOB, 0, 0));
+                        }
+                        r[it] = make_float4(ev[0], ev[1], ev[2], ev[3]);
+                    }
+                }
+                return;
+            }
+        }
         if constexpr (std::is_same<ADDR, PatchKcAddr>::value) {
             if (cg.kcUniform) {   // workgroup-uniform branch
                 const PatchKcAddr::Tile t = PatchKcAddr::tile(cg, k0);
@@ -514,6 +612,17 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
     }
 #endif
+    // k table of the B loader (d.ktabN entries behind the stages and the bias column): built by all 512 threads, visible to the
+    // producers after one workgroup barrier that every wave passes before the roles split
+    const int2* ktab = nullptr;
+    if constexpr (has_ktab<BADDR>::value) {
+        if (d.ktabN) {
+            int2* tab = reinterpret_cast<int2*>(smem + 3 * STAGE + BM);
+            for (int k = threadIdx.x; k < d.ktabN; k += 2 * THREADS) tab[k] = BADDR::ktab_entry(cg, k < d.Kg ? k : 0);
+            ktab = tab;
+            lds_done_barrier();
+        }
+    }
     if (threadIdx.x >= THREADS) {
         // ------------------------------ producer waves ------------------------------
         // Register ring of NS tile sets: tile u lives in set u % NS and goes to LDS stage u % 3.  Tiles 0
@@ -538,18 +647,21 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         // loaders' per-column decode stays hoisted out of the K loop (conv2 backward-data is bound by this arithmetic).
         int fk = 0, fj0 = coff + col_block(blockIdx.x) * BN, ft = blockIdx.x;
         const int j0c = fj0;
+        KCol bcols[LB::NCH];   // K-table loaders: the column part of this thread's chunks of the current tile
+        if (ktab && VEC == 4) LB::prep_cols(bcols, pb, cg, g, fj0, jlim, tid);
         auto fetch = [&](auto& la, auto& lb, int u) {
             if (PERSIST) {
                 la.fetch(ra, pa, cg, g, b, kbeg + fk * BK, kend, i0, ilim, tid);
-                lb.fetch(rb, pb, cg, g, b, kbeg + fk * BK, kend, fj0, jlim, tid);
+                lb.fetch(rb, pb, cg, g, b, kbeg + fk * BK, kend, fj0, jlim, tid, ktab, bcols);
                 if (++fk == nkTile) {
                     fk = 0;
                     ft += gridDim.x;
                     fj0 = coff + col_block(ft) * BN;
+                    if (ktab && VEC == 4) LB::prep_cols(bcols, pb, cg, g, fj0, jlim, tid);
                 }
             } else {
                 la.fetch(ra, pa, cg, g, b, kbeg + u * BK, kend, i0, ilim, tid);
-                lb.fetch(rb, pb, cg, g, b, kbeg + u * BK, kend, j0c, jlim, tid);
+                lb.fetch(rb, pb, cg, g, b, kbeg + u * BK, kend, j0c, jlim, tid, ktab, bcols);
             }
         };
         auto commit = [&](const auto& la, const auto& lb, int stage) {
@@ -935,18 +1047,27 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     typedef Loader<AADDR, BM, BK, VEC> LA;
     typedef Loader<BADDR, BN, BK, VEC> LB;
-    constexpr size_t lds = (3 * (LA::LDS_FLOATS + LB::LDS_FLOATS) + BM) * sizeof(float);   // three stages + the tile's bias column
-    static_assert(lds <= 160 * 1024, "LDS budget");
+    constexpr size_t ldsTile = (3 * (LA::LDS_FLOATS + LB::LDS_FLOATS) + BM) * sizeof(float);   // three stages + the tile's bias column
+    static_assert(ldsTile <= 160 * 1024, "LDS budget");
     auto kern = mc_igemm<AADDR, BADDR, MT, NT, WM, WN, BK, VEC, NS, EPI, KQ>;
     Dims d = d0;
+    // the B loader's k table (8 bytes per k, padded to whole K tiles + one tile of slack for the k tail of a chunk)
+    static const bool noktab = getenv("MC_IGEMM_NOKTAB") != nullptr;
+    d.ktabN = 0;
+    if (has_ktab<BADDR>::value && !noktab && d.Kg <= KTAB_MAX && d.batches == 1) {
+        const int n = (ceil_div(d.Kg, BK) + 1) * BK;
+        if (ldsTile + (size_t)n * 8 <= 160 * 1024) d.ktabN = n;
+    }
+    const size_t lds = ldsTile + (size_t)d.ktabN * 8;
+    constexpr size_t ldsMax = has_ktab<BADDR>::value ? (ldsTile + (size_t)(KTAB_MAX + 2 * BK) * 8 <= 160 * 1024 ? ldsTile + (size_t)(KTAB_MAX + 2 * BK) * 8 : 160 * 1024) : ldsTile;
     // per-device state of this instantiation (a function attribute belongs to the device's own code object)
     static std::atomic<unsigned long long> attrDone{0};
     static std::atomic<int> perCU[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
     dev &= 63;
-    if (lds > 48 * 1024 && !((attrDone.load(std::memory_order_acquire) >> dev) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ldsMax > 48 * 1024 && !((attrDone.load(std::memory_order_acquire) >> dev) & 1ull)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsMax);
         attrDone.fetch_or(1ull << dev, std::memory_order_release);
     }
     dim3 grid(ceil_div(d.Ng, BN), ceil_div(d.Mg, BM), chunks * d.groups * d.batches);
@@ -956,11 +1077,13 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
     const int stepsPerTile = ceil_div(d.kChunk < d.Kg ? d.kChunk : d.Kg, BK);
     static const bool nopersist = getenv("MC_IGEMM_NOPERSIST") != nullptr;
     if (KQ == 1 && !nopersist && stepsPerTile <= 24 && (long)grid.x * grid.y * grid.z > 2L * num_cus()) {
-        int pc = perCU[dev].load(std::memory_order_relaxed);
+        // resident workgroups per CU at this LDS footprint (it varies with the k table): cached as (lds << 8 | count)
+        const int cached = perCU[dev].load(std::memory_order_relaxed);
+        int pc = (cached >> 8) == (int)(lds >> 8) ? (cached & 0xFF) : 0;
         if (pc == 0) {
             int nb = 0;
-            pc = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 2 * THREADS, lds) == hipSuccess && nb > 0) ? nb : 1;
-            perCU[dev].store(pc, std::memory_order_relaxed);
+            pc = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 2 * THREADS, lds) == hipSuccess && nb > 0) ? (nb > 255 ? 255 : nb) : 1;
+            perCU[dev].store((int)((lds >> 8) << 8) | pc, std::memory_order_relaxed);
         }
         long workers = (long)pc * num_cus() / ((long)grid.y * grid.z);
         if (workers >= 8) workers = workers / 8 * 8;

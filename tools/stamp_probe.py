@@ -44,5 +44,7 @@ if which == "gemm":
     gemm(96, 131072, 160, 0, 0, "cccp2 fwd"); gemm(160, 131072, 96, 1, 0, "cccp2 bwd"); gemm(96, 160, 131072, 0, 1, "cccp2 wgrad")
     gemm(192, 32768, 192, 0, 0, "cccp3 fwd"); gemm(192, 32768, 192, 1, 0, "cccp3 bwd"); gemm(192, 192, 32768, 0, 1, "cccp3 wgrad")
     gemm(192, 8192, 192, 0, 0, "cccp5 fwd"); gemm(192, 8192, 192, 1, 0, "cccp5 bwd"); gemm(192, 192, 8192, 0, 1, "cccp5 wgrad")
+elif which == "small":   # layers-80sec: 3 -> 32 on 32x32, 32 -> 32 on 16x16, 32 -> 64 on 8x8, all 5x5 pad 2
+    conv("80s conv1", 3, 32, 5, 32, 2, "fw"); conv("80s conv2", 32, 16, 5, 32, 2); conv("80s conv3", 32, 8, 5, 64, 2)
 else:
     conv("conv1", 3, 32, 5, 192, 2, "fw"); conv("conv2", 96, 16, 5, 192, 2); conv("conv3", 192, 8, 3, 192, 1)
