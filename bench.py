@@ -78,6 +78,7 @@ def main():
         torch.cuda.synchronize()
 
     libkernel.setProfile("conv2/fwd:mc_conv_filter_acts_relu_bits")
+    libkernel.getProfile()                                          # clears the communicator's counters: they cover the timed steps only
     barrier()
     t0 = time.perf_counter()
     libkernel.startResident(0, a.warmup % nres, a.steps)
@@ -98,6 +99,10 @@ def main():
     libkernel.finishBatch()
     table = libkernel.getProfile()
     libkernel.setProfile("")
+    # counters that ride in the same dict are not kernels
+    counters = dict((k, prof.pop(k)) for k in list(prof) if k.startswith(("dp/", "net/step_graph")))
+    for k in [k for k in table if k.startswith(("dp/", "net/step_graph"))]:
+        table.pop(k)
 
     if rank != 0:
         return
@@ -161,6 +166,13 @@ def main():
     }
     if traffic_note:
         out["roofline"]["traffic_note"] = traffic_note
+    if "dp/allreduce:bytes" in counters:   # gradient all-reduce of the timed steps (rank 0's communicator)
+        calls, nbytes = counters["dp/allreduce:bytes"]
+        wsteps, wait_ms = counters.get("dp/wait:ms", (0, 0.0))
+        out["dp"] = {"allreduce_calls_per_step": calls / float(a.steps), "allreduce_bytes_per_step": nbytes / float(a.steps),
+                     "exposed_wait_ms_per_step": wait_ms / max(wsteps, 1),
+                     "note": "buckets of >= 1 MiB of completed gradients reduced on a side stream during back-propagation; the wait is how long the "
+                             "compute stream stalled on them before the weight update (HIP events)"}
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(modelutil)
     print(json.dumps(out))
