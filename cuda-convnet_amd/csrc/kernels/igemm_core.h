@@ -1261,6 +1261,10 @@ int launch_rows_cols_epi(const typename AADDR::P& pa, const typename BADDR::P& p
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    // hysteresis: the rule's tile stays unless another one is at least 3 % faster -- two tiles within timing noise of each other
+    // would otherwise trade places from run to run (NIN conv2 forward: 96x128 and 192x128), and with them the launch that
+    // profiles and benchmarks talk about
+    if (ms[rule] >= 0.f && ms[rule] <= bestMs * 1.03f) best = rule;
     if (mode >= 2) {
         fprintf(stderr, "[mc_igemm autotune] %s rows %d cols %d k %d chunks %d batches %d:",
                 AADDR::KC ? (BADDR::KC ? "kc/kc" : "kc/nat") : (BADDR::KC ? "nat/kc" : "nat/nat"),

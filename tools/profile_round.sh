@@ -15,7 +15,7 @@ for net in imagenet 80sec conv-local; do
   C="python3 tools/net_bench.py $net 128 20"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/trace_$net -o $net -- $C > $out/trace_$net.log 2>&1 || { echo "trace $net failed"; tail -5 $out/trace_$net.log; exit 1; }
   python3 tools/rocprof_summary.py $(find $out/trace_$net -name "${net}_results.db" | head -1) $out/${tag}_$(echo $net | tr -d '-')_bs128_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- $C" || exit 1
-  grep -v amdgpu.ids $out/trace_$net.log | tail -12 > $out/${tag}_$(echo $net | tr -d '-')_bs128_net_bench.txt
+  grep -A10 "images/s" $out/trace_$net.log > $out/${tag}_$(echo $net | tr -d '-')_bs128_net_bench.txt
 done
 S="python3 bench.py --steps 4 --warmup 1 --resident-minibatches 2 --no-cpu-baseline"
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch -o nin -- $S > $out/pmc_fetch.log 2>&1 || { echo "pmc fetch failed"; tail -5 $out/pmc_fetch.log; exit 1; }
