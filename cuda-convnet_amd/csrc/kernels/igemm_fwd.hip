@@ -52,6 +52,11 @@ int conv_split_plan(int rows, long cols, int K, int groups, int* kChunkOut) {
     // (measured and dropped: aiming at 2-4 workgroups per CU for products with <= 64 rows -- layers-80sec conv2 forward, 256 tiles
     // -- by splitting further: no faster, the extra reduction eats what the split gains)
     long chunks = num_cus() / tiles;
+    // Between half and all of the CUs covered, one workgroup each: every SIMD's matrix pipe hangs on a single wave's LDS
+    // latency and nothing overlaps the workgroups' prologues and stores.  With a long K, two half-K workgroups per CU and a
+    // reduction are faster (NIN conv2 backward-data, 256 tiles x K = 4800: 296 -> 271 us).  Aiming at two per CU everywhere
+    // was measured too and loses on the short products (conv3 forward 69 -> 75 us).
+    if (chunks < 2 && 2 * tiles > num_cus() && tiles <= num_cus() && K >= 2048) chunks = 2;
     *kChunkOut = 0;
     if (chunks < 2 || K < 512) return 1;
     if (chunks > 8) chunks = 8;
