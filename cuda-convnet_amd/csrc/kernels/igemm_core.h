@@ -651,6 +651,9 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         if (ktab && VEC == 4) LB::prep_cols(bcols, pb, cg, g, fj0, jlim, tid);
         auto fetch = [&](auto& la, auto& lb, int u) {
             if (PERSIST) {
+#ifdef MC_ABL_A_ONCE   // timing-only ablation: the A operand is fetched for a worker's first column tile only (wrong results)
+                if (ft == (int)blockIdx.x)
+#endif
                 la.fetch(ra, pa, cg, g, b, kbeg + fk * BK, kend, i0, ilim, tid);
                 lb.fetch(rb, pb, cg, g, b, kbeg + fk * BK, kend, fj0, jlim, tid, ktab, bcols);
                 if (++fk == nkTile) {

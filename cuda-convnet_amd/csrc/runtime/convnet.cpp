@@ -142,9 +142,7 @@ DevMatV& DataProvider::getDataSlice(int startCase, int endCase) {
     const int n = endCase - startCase;
     if (n <= 0) throw std::runtime_error("empty data slice");
     _miniV.clear();
-    static const bool nostage = getenv("MC_EXPERIMENT_NOSTAGE") != nullptr;   // timing experiment only: stale minibatch contents
     for (size_t i = 0; i < _data.size(); i++) {
-        if (nostage && _mini[i]->cols() == n && _mini[i]->rows() == _data[i]->rows()) { _miniV.push_back(_mini[i]); continue; }
         DevMat& src = *_data[i];
         DevMat& dst = *_mini[i];
         dst.resize(src.rows(), n);

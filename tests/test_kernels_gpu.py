@@ -382,6 +382,29 @@ def test_softmax_logreg(N, K):
     assert np.array_equal(host(pf2), hp) and np.array_equal(host(sf), host(sums))
 
 
+def test_accumulate_f64_and_autotune_switch():
+    """mc_accumulate_f64: dst += src in double (the device-side running cost total of captured training steps); mc_set_autotune:
+    with the timed tile trial off a first-seen shape still gives the same bits (the rule's tile), and turning it back on works."""
+    import torch
+    m = mc()
+    a = torch.tensor([1.5, -2.25, 1e-9], dtype=torch.float64, device="cuda")
+    b = torch.tensor([1e9, 0.125, 3.0], dtype=torch.float64, device="cuda")
+    m.call("mc_accumulate_f64", a.data_ptr(), b.data_ptr(), 3, None)
+    m.call("mc_accumulate_f64", a.data_ptr(), b.data_ptr(), 3, None)
+    torch.cuda.synchronize()
+    assert a.cpu().tolist() == [1.5 + 2e9, -2.0, 1e-9 + 6.0]
+    rng = np.random.default_rng(77)
+    mm, nn, kk = 72, 1160, 136                      # a shape no other test uses: not in the tuner's cache yet
+    A, B = dev(rng.standard_normal((mm, kk)).astype(np.float32)), dev(rng.standard_normal((kk, nn)).astype(np.float32))
+    off, on = nans(mm, nn), nans(mm, nn)
+    m.call("mc_set_autotune", 0)
+    m.call("mc_gemm", ptr(A), ptr(B), ptr(off), mm, nn, kk, 0, 0, kk, nn, nn, 0.0, 1.0, None, m.NEURON_NONE, None, 0, None)
+    m.call("mc_set_autotune", 1)
+    m.call("mc_gemm", ptr(A), ptr(B), ptr(on), mm, nn, kk, 0, 0, kk, nn, nn, 0.0, 1.0, None, m.NEURON_NONE, None, 0, None)
+    assert np.array_equal(host(off), host(on))
+    assert relerr(host(on), G.matmul(host(A), host(B))) < TOL
+
+
 def test_weights_update():
     m = mc()
     rng = np.random.default_rng(22)
