@@ -438,25 +438,42 @@ struct Loader {
         }
     }
 
+    // TAB: the K-table form (a compile-time choice: a run-time branch here would sit inside the producers' K loop, where the
+    // compiler's vmcnt bookkeeping must stay exact -- with the branch it waited for vmcnt(3) instead of vmcnt(6) before every
+    // commit and drained to vmcnt(0) in the arithmetic path, i.e. one tile in flight instead of three)
+    template <bool TAB = false>
     __device__ __forceinline__ void fetch(__amdgpu_buffer_rsrc_t rs, const P& p, const ConvG& cg, int g, int b, int k0, int kend,
                                           int x0, int xlim, int tid, const int2* ktab = nullptr, const KCol* cols = nullptr) {
 #ifdef MC_ABL_NOFETCH   // timing-only ablation builds (tools/build_variant.sh); wrong results
         if (k0 > 0) return;
 #endif
-        if constexpr (has_ktab<ADDR>::value) {
-            if (ktab) {   // workgroup-uniform: the k part of the address comes from the table (see KCol)
+        if constexpr (has_ktab<ADDR>::value && TAB) {
+            {   // the k part of the address comes from the table (see KCol)
                 const unsigned limY = (unsigned)ADDR::ktab_limY(cg), limX = (unsigned)ADDR::ktab_limX(cg);
+                // all table reads first, as whole 8-byte entries, and pinned: left to itself the compiler sinks the read of the
+                // offset half into the "element is valid" branch -- two dependent LDS round trips and an exec-mask dance per chunk
+                int2 ent[NCH];
+#pragma unroll
+                for (int it = 0; it < NCH; ++it) {
+                    int dk, dx;
+                    chunk_pos(tid + it * THREADS, dk, dx);
+                    ent[it] = ktab[k0 + dk];   // the table is padded to a whole K tile
+                }
+#pragma unroll
+                for (int it = 0; it < NCH; ++it) asm volatile("" : "+v"(ent[it].x), "+v"(ent[it].y));
 #pragma unroll
                 for (int it = 0; it < NCH; ++it) {
                     const int c = tid + it * THREADS;
                     int dk, dx;
                     chunk_pos(c, dk, dx);
                     const int k = k0 + dk;
-                    const int2 e = ktab[k];   // the table is padded to a whole K tile
+                    const int2 e = ent[it];
                     const int dy = (int)(short)(e.y & 0xFFFF), dxx = e.y >> 16;
                     if (VEC == 4) {   // the column part was decoded once per tile (prep_cols)
                         const bool ok = ((unsigned)(cols[it].cy + dy) < limY) & ((unsigned)(cols[it].cx + dxx) < limX) & (k < kend);
-                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)(cols[it].base + e.x) * 4u : OOB, 0, 0);
+                        unsigned off = (unsigned)(cols[it].base + e.x) * 4u;
+                        off = ok ? off : OOB;
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
                         r[it] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
                     } else {
                         const bool live = CHUNKS % THREADS == 0 || c < CHUNKS;
@@ -637,8 +654,9 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         __builtin_amdgcn_s_setprio(3);
 #endif
         const __amdgpu_buffer_rsrc_t ra = make_rsrc(AADDR::base(pa), pa.bytes), rb = make_rsrc(BADDR::base(pb), pb.bytes);
-        auto produce = [&](auto persist_) {
+        auto produce = [&](auto persist_, auto tab_) {
         constexpr bool PERSIST = decltype(persist_)::value;
+        constexpr bool TAB = decltype(tab_)::value;   // the B loader reads the k part of its addresses from the LDS table
         LA as[NS];
         LB bs[NS];
         // Persistent workers (several column tiles per workgroup): fetches are issued in step order (u = 0, 1, 2, ...),
@@ -648,23 +666,23 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         int fk = 0, fj0 = coff + col_block(blockIdx.x) * BN, ft = blockIdx.x;
         const int j0c = fj0;
         KCol bcols[LB::NCH];   // K-table loaders: the column part of this thread's chunks of the current tile
-        if (ktab && VEC == 4) LB::prep_cols(bcols, pb, cg, g, fj0, jlim, tid);
+        if (TAB && VEC == 4) LB::prep_cols(bcols, pb, cg, g, fj0, jlim, tid);
         auto fetch = [&](auto& la, auto& lb, int u) {
             if (PERSIST) {
 #ifdef MC_ABL_A_ONCE   // timing-only ablation: the A operand is fetched for a worker's first column tile only (wrong results)
                 if (ft == (int)blockIdx.x)
 #endif
                 la.fetch(ra, pa, cg, g, b, kbeg + fk * BK, kend, i0, ilim, tid);
-                lb.fetch(rb, pb, cg, g, b, kbeg + fk * BK, kend, fj0, jlim, tid, ktab, bcols);
+                lb.template fetch<TAB>(rb, pb, cg, g, b, kbeg + fk * BK, kend, fj0, jlim, tid, ktab, bcols);
                 if (++fk == nkTile) {
                     fk = 0;
                     ft += gridDim.x;
                     fj0 = coff + col_block(ft) * BN;
-                    if (ktab && VEC == 4) LB::prep_cols(bcols, pb, cg, g, fj0, jlim, tid);
+                    if (TAB && VEC == 4) LB::prep_cols(bcols, pb, cg, g, fj0, jlim, tid);
                 }
             } else {
                 la.fetch(ra, pa, cg, g, b, kbeg + u * BK, kend, i0, ilim, tid);
-                lb.fetch(rb, pb, cg, g, b, kbeg + u * BK, kend, j0c, jlim, tid, ktab, bcols);
+                lb.template fetch<TAB>(rb, pb, cg, g, b, kbeg + u * BK, kend, j0c, jlim, tid, ktab, bcols);
             }
         };
         auto commit = [&](const auto& la, const auto& lb, int stage) {
@@ -731,8 +749,16 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
             }
         }
         };
-        if ((int)gridDim.x == d.colTiles) produce(std::false_type{});
-        else produce(std::true_type{});
+        const bool onePerTile = (int)gridDim.x == d.colTiles;
+        if constexpr (has_ktab<BADDR>::value) {
+            if (ktab) {
+                if (onePerTile) produce(std::false_type{}, std::true_type{});
+                else produce(std::true_type{}, std::true_type{});
+                return;
+            }
+        }
+        if (onePerTile) produce(std::false_type{}, std::false_type{});
+        else produce(std::true_type{}, std::false_type{});
         return;
     }
 
