@@ -139,10 +139,11 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f)
-        if pmc.get("launch") == launched:
-            traffic = pmc["hbm_bytes_per_launch"]
+        known = pmc.get("launches", {pmc.get("launch"): pmc})      # one entry per launch the autotuner may pick
+        if launched in known:
+            traffic = known[launched]["hbm_bytes_per_launch"]
         else:
-            traffic_note = "STALE profiles/pmc_traffic.json: counters were collected on [%s], this run launched [%s]" % (pmc.get("launch"), launched)
+            traffic_note = "STALE profiles/pmc_traffic.json: counters were collected on %s, this run launched [%s]" % (sorted(str(k) for k in known), launched)
             sys.stderr.write("bench.py: " + traffic_note + " -- roofline.traffic withheld; re-run tools/profile_round.sh\n")
     except (OSError, KeyError, ValueError) as e:
         traffic_note = "profiles/pmc_traffic.json unreadable: %s" % e

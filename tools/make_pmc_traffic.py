@@ -9,6 +9,7 @@ import re
 import sys
 
 fetch_f, write_f, sq_f, bench_f, stats_f = sys.argv[1:6]
+merge_f = sys.argv[6] if len(sys.argv) > 6 else None      # an existing pmc_traffic.json to add this launch to
 bench = json.load(open(bench_f))
 launch = bench["roofline"]["launch"]
 m = re.match(r"(mc_igemm<[^>]*>) grid=\((\d+),(\d+),(\d+)\)", launch)
@@ -57,7 +58,7 @@ hbm = int((2 * f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024)
 busy = None
 if "SQ_VALU_MFMA_BUSY_CYCLES" in sq and "SQ_BUSY_CYCLES" in sq and sq["SQ_BUSY_CYCLES"] > 0:
     busy = sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (sq["SQ_BUSY_CYCLES"] / 32.0 * 1024.0)
-json.dump({
+entry = {
     "launch": launch,
     "what": "NIN conv2 forward (192 x 32768 x 2400 implicit GEMM + bias + relu + relu bit mask), the launch bench.py's roofline times",
     "fetch_size_kib": f["FETCH_SIZE"], "write_size_kib": w["WRITE_SIZE"], "hbm_bytes_per_launch": hbm,
@@ -68,4 +69,16 @@ json.dump({
     "profiled_avg_us": {"fetch_pass": f_us, "write_pass": w_us, "sq_pass": s_us},
     "kernel_trace_avg_us": trace_us, "bench_event_avg_us": want_us,
     "source": [fetch_f.split("/")[-1], write_f.split("/")[-1], sq_f.split("/")[-1], stats_f.split("/")[-1]],
-}, sys.stdout, indent=1)
+}
+# The autotuner's pick for conv2 forward moves between two tiles that time within a few per cent of each other, so the file
+# holds one entry per launch it may make; bench.py reports the traffic of the one it actually timed.
+out = {"launches": {}}
+if merge_f:
+    try:
+        out = json.load(open(merge_f))
+        if "launches" not in out:
+            out = {"launches": {out["launch"]: out}} if "launch" in out else {"launches": {}}
+    except (OSError, ValueError):
+        pass
+out["launches"][launch] = entry
+json.dump(out, sys.stdout, indent=1)

@@ -21,7 +21,7 @@ S="python3 bench.py --steps 4 --warmup 1 --resident-minibatches 2 --no-cpu-basel
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch -o nin -- $S > $out/pmc_fetch.log 2>&1 || { echo "pmc fetch failed"; tail -5 $out/pmc_fetch.log; exit 1; }
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write -o nin -- $S > $out/pmc_write.log 2>&1 || { echo "pmc write failed"; tail -5 $out/pmc_write.log; exit 1; }
 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT -d $out/pmc_sq -o nin -- $S > $out/pmc_sq.log 2>&1 || { echo "pmc sq failed"; tail -5 $out/pmc_sq.log; exit 1; }
-for p in fetch write sq; do
+for p in fetch write sq; do   # (tools/profile_pmc.sh collects the same per candidate tile and writes the pmc_traffic.json that is committed)
   python3 tools/pmc_summary.py $(find $out/pmc_$p -name 'nin_results.db' | head -1) mc_ --out $out/${tag}_nin_bs128_pmc_$p.txt || exit 1
 done
 timeout -k 10 300 python3 bench.py --steps 50 --warmup 10 --kernel-table $out/${tag}_nin_bs128_event_table.json > $out/${tag}_bench_n1.json 2> $out/bench.err || { echo "bench failed"; tail -5 $out/bench.err; exit 1; }
