@@ -40,7 +40,14 @@ BASE_OPTIONS = [
 
 
 class ModelStateException(Exception):
-    pass
+    """Raised by a subclass's init_model_state when a checkpoint and the command line cannot be reconciled."""
+
+
+def _quit(*lines, code=None):
+    """Prints what went wrong and ends the process the way the reference driver does (its callers script against the exit)."""
+    for line in lines:
+        print(line)
+    sys.exit(code)
 
 
 class IGPUModel(object):
@@ -48,115 +55,118 @@ class IGPUModel(object):
         self.model_name, self.op, self.options = model_name, op, op.options
         self.load_dic, self.filename_options = load_dic, filename_options
         self.dp_params = {} if dp_params is None else dp_params
-        self.range_train_outputs = []
-        self.get_gpus()
-        self.fill_excused_options()
-        for opt in op.get_options_list():           # every option is an attribute of the model
-            setattr(self, opt.name, opt.value)
-
-        if load_dic:
-            self.model_state = load_dic["model_state"]
-            given = self.options["load_file"].value
-            self.save_file = given if os.path.isdir(given) else os.path.dirname(given)
+        resumed = bool(load_dic)
+        self.range_train_outputs = list()
+        self.get_gpus(); self.fill_excused_options()
+        vars(self).update((opt.name, opt.value) for opt in op.get_options_list())   # every option is an attribute of the model
+        if resumed:
+            self._resume_from(load_dic)
         else:
-            self.model_state = {"train_outputs": [], "test_outputs": [], "epoch": 1, "batchnum": self.train_batch_range[0]}
-            if filename_options is not None:
-                tags = ["%s_%s" % (char, self.options[name].get_str_value()) for name, char in filename_options]
-                # "<model>_<c_value>_..._<time>"; with no tags the two separators stay ("ConvNet__<time>"), as tools expect
-                self.save_file = "%s_%s_%s" % (model_name, "_".join(tags), time.strftime("%Y-%m-%d_%H.%M.%S"))
-
+            self._start_fresh(filename_options)
         self.init_data_providers()
-        if load_dic:
-            self.train_data_provider.advance_batch()    # the checkpoint names the last batch that was trained on
+        if resumed:                                  # the checkpoint names the last batch that was trained on
+            self.train_data_provider.advance_batch()
         try:
             self.init_model_state()
-        except ModelStateException as e:
-            print(e)
-            sys.exit(1)
-        self.__dict__.update(self.model_state)      # epoch, batchnum, train_outputs, ... live on the model while it runs
-        self.import_model()
-        self.init_model_lib()
+        except ModelStateException as problem:
+            _quit(problem, code=1)
+        vars(self).update(self.model_state)          # epoch, batchnum, train_outputs, ... live on the model while it runs
+        self.import_model(); self.init_model_lib()
+
+    def _resume_from(self, checkpoint):
+        self.model_state = checkpoint["model_state"]
+        given = self.options["load_file"].value
+        self.save_file = given if os.path.isdir(given) else os.path.dirname(given)
+
+    def _start_fresh(self, filename_options):
+        self.model_state = dict(train_outputs=[], test_outputs=[], epoch=1, batchnum=self.train_batch_range[0])
+        if filename_options is None:
+            return
+        tags = ["%s_%s" % (char, self.options[name].get_str_value()) for name, char in filename_options]
+        # "<model>_<c_value>_..._<time>"; with no tags the two separators stay ("ConvNet__<time>"), as tools expect
+        self.save_file = "%s_%s_%s" % (self.model_name, "_".join(tags), time.strftime("%Y-%m-%d_%H.%M.%S"))
 
     # ---------------------------------------------------------------- hooks
     def import_model(self):
         print(RULE)
         print("Importing _%s C++ module" % self.model_name)
-        self.libmodel = __import__("_" + self.model_name)
+        self.libmodel = __import__("_%s" % self.model_name)
 
     def fill_excused_options(self):
-        pass
+        """Give values to options that an EXCLUDE/REQUIRE relation excused from the command line."""
 
     def init_model_state(self):
-        pass
+        """Build (fresh run) or reconcile (resumed run) `model_state`; may raise ModelStateException."""
 
     def init_model_lib(self):
-        pass
+        """Hand the model to the native module."""
 
     def print_model_state(self):
-        pass
+        """Describe the model at the top of a training run."""
 
     def print_mean_cost(self, costs):
-        pass
+        """Print the mean of a list of finishBatch results."""
 
     def init_data_providers(self):
-        self.dp_params["convnet"] = self
+        self.dp_params.update(convnet=self)
         common = dict(type=self.dp_type, dp_params=self.dp_params)
+        at = self.model_state
         try:
             self.test_data_provider = DataProvider.get_instance(self.data_path, self.test_batch_range, test=True, **common)
-            self.train_data_provider = DataProvider.get_instance(self.data_path, self.train_batch_range, self.model_state["epoch"],
-                                                                 self.model_state["batchnum"], test=False, **common)
-        except DataProviderException as e:
-            print("Unable to create data provider: %s" % e)
+            self.train_data_provider = DataProvider.get_instance(self.data_path, self.train_batch_range, at["epoch"], at["batchnum"],
+                                                                 test=False, **common)
+        except DataProviderException as problem:
+            print("Unable to create data provider: %s" % problem)
             self.print_data_providers()
-            sys.exit()
+            _quit()
 
     # ---------------------------------------------------------------- the cycle
     def start(self):
         if not self.test_only:
             return self.train()
         self.test_outputs.append(self.get_test_error())
-        self.print_test_results()
-        sys.exit(0)
+        self.print_test_results(); _quit(code=0)
 
     def train(self):
-        for line in (RULE, "Training %s" % self.model_name):
-            print(line)
-        self.op.print_values()
-        print(RULE)
-        self.print_model_state()
-        print("Running on device(s) %s" % ", ".join(str(d) for d in self.device_ids))
-        print("Current time: %s" % time.asctime(time.localtime()))
-        print("Saving checkpoints to %s" % os.path.join(self.save_path, self.save_file))
-        print(RULE)
-        self.range_train_outputs = []
+        self._print_banner()
+        del self.range_train_outputs[:]
         upcoming = self.get_next_batch()
-        while self.epoch <= self.num_epochs:
+        while self.num_epochs >= self.epoch:
             batch, began = upcoming, time.time()
-            self.epoch, self.batchnum = batch[0], batch[1]
-            self.print_iteration()
-            sys.stdout.flush()
+            self.epoch, self.batchnum = batch[:2]
+            self.print_iteration(); sys.stdout.flush()
             self.start_batch(batch)
             upcoming = self.get_next_batch()            # host I/O while the device trains
             result = self.finish_batch()
-            self.train_outputs.append(result)
-            self.range_train_outputs.append(result)
+            for history in (self.train_outputs, self.range_train_outputs):
+                history.append(result)
             self.print_train_results()
-            if self.get_num_batches_done() % self.testing_freq == 0:
+            if not self.get_num_batches_done() % self.testing_freq:
                 self.test_and_checkpoint()
             self.print_train_time(time.time() - began)
         self.cleanup()
 
+    def _print_banner(self):
+        print("%s\nTraining %s" % (RULE, self.model_name))
+        self.op.print_values()
+        print(RULE)
+        self.print_model_state()
+        print("Running on device(s) %s" % ", ".join(map(str, self.device_ids)))
+        print("Current time: %s" % time.asctime(time.localtime()))
+        print("Saving checkpoints to %s" % os.path.join(self.save_path, self.save_file))
+        print(RULE)
+
     def test_and_checkpoint(self):
+        """What happens every `testing_freq` batches: a test pass, the report, a checkpoint if the test error allows one."""
         self.sync_with_host()
         self.test_outputs.append(self.get_test_error())
         self.print_mean_train_results()
-        self.range_train_outputs = []
-        self.print_test_results()
-        self.print_test_status()
-        self.conditional_save()
+        self.range_train_outputs = list()
+        for report in (self.print_test_results, self.print_test_status, self.conditional_save):
+            report()
 
     def cleanup(self):
-        sys.exit(0)
+        _quit(code=0)
 
     def sync_with_host(self):
         self.libmodel.syncWithHost()
@@ -189,8 +199,7 @@ class IGPUModel(object):
             upcoming = self.get_next_batch(train=False) if more else None
             results.append(self.finish_batch())
             if self.test_only:
-                print("batch %d: %s" % (batch[1], str(results[-1])))
-            sys.stdout.flush()
+                print("batch %d: %s" % (batch[1], results[-1]), flush=True)
             batch = upcoming
         return self.aggregate_test_outputs(results)
 
@@ -213,8 +222,7 @@ class IGPUModel(object):
         print("Train error: %.6f " % cost, end=" ")
 
     def print_mean_train_results(self):
-        print("\n======================Train output======================")
-        print("mean train cost: ", end=" ")
+        print("\n======================Train output======================\nmean train cost: ", end=" ")
         self.print_mean_cost(self.range_train_outputs)
 
     def print_test_results(self):
@@ -225,22 +233,22 @@ class IGPUModel(object):
         print("ok" if len(errs) == 1 or errs[1] < errs[0] else "WORSE", end=" ")
 
     def conditional_save(self):
-        if 0 < self.test_outputs[-1][0] < self.max_test_err:
-            self.save_state()
-        else:
-            print("\tTest error > %g, not saving." % self.max_test_err, end=" ")
+        if not 0 < self.test_outputs[-1][0] < self.max_test_err:
+            return print("\tTest error > %g, not saving." % self.max_test_err, end=" ")
+        self.save_state()
 
     # ---------------------------------------------------------------- state
     def set_var(self, var_name, var_val):
-        self.model_state[var_name] = var_val
+        """Model variables live twice while the model runs: in `model_state` (what a checkpoint holds) and as attributes."""
         setattr(self, var_name, var_val)
+        self.model_state.update({var_name: var_val})
         return var_val
 
     def get_var(self, var_name):
-        return self.model_state[var_name]
+        return self.model_state.__getitem__(var_name)
 
     def has_var(self, var_name):
-        return var_name in self.model_state
+        return self.model_state.__contains__(var_name)
 
     def save_state(self):
         for key in self.model_state:                # pull the running values back into the state dict
@@ -252,49 +260,45 @@ class IGPUModel(object):
 
     @staticmethod
     def load_checkpoint(load_dir):
-        if not os.path.isdir(load_dir):
-            return unpickle(load_dir)
-        newest = max(os.listdir(load_dir), key=alphanum_key)
-        return unpickle(os.path.join(load_dir, newest))
+        """A checkpoint file, or the newest file ("<epoch>.<batch>", natural order) of a checkpoint directory."""
+        if os.path.isdir(load_dir):
+            load_dir = os.path.join(load_dir, max(os.listdir(load_dir), key=alphanum_key))
+        return unpickle(load_dir)
 
     # ---------------------------------------------------------------- options
     @staticmethod
     def get_options_parser():
-        op = OptionsParser()
-        for flag, attr, parser, desc, kw in BASE_OPTIONS:
-            op.add_option(flag, attr, parser, desc, **kw)
-        return op
+        parser = OptionsParser()
+        for flag, attr, kind, desc, kw in BASE_OPTIONS:
+            parser.add_option(flag, attr, kind, desc, **kw)
+        return parser
 
     @staticmethod
     def print_data_providers():
-        print("Available data providers:")
-        for name in dp_types:
-            print("    %s: %s" % (name, dp_types[name]))
+        print("\n".join(["Available data providers:"] + ["    %s: %s" % item for item in dp_types.items()]))
 
     def get_gpus(self):
-        self.device_ids = [get_gpu_lock(g) for g in self.op.get_value("gpu")]
-        if GPU_LOCK_NO_LOCK in self.device_ids:
-            print("Not enough free GPUs!")
-            sys.exit()
+        self.device_ids = list(map(get_gpu_lock, self.op.get_value("gpu")))
+        if any(d == GPU_LOCK_NO_LOCK for d in self.device_ids):
+            _quit("Not enough free GPUs!")
 
     @staticmethod
     def parse_options(op, argv=None):
         """(options, checkpoint or None); with -f the checkpoint's options are the defaults and the command line overrides."""
+        checkpoint = None
         try:
-            load_dic = None
             given = op.parse(argv=argv)
             if given["load_file"].value_given:
-                load_dic = IGPUModel.load_checkpoint(given["load_file"].value)
-                load_dic["op"].merge_from(op)
-                op = load_dic["op"]
+                checkpoint = IGPUModel.load_checkpoint(given["load_file"].value)
+                checkpoint["op"].merge_from(op)
+                op = checkpoint["op"]
             op.eval_expr_defaults()
-            return op, load_dic
-        except OptionMissingException as e:
-            print(e)
+        except OptionMissingException as problem:
+            print(problem)
             op.print_usage()
-        except OptionException as e:
-            print(e)
-        except UnpickleError as e:
-            print("Error loading checkpoint:")
-            print(e)
-        sys.exit()
+            _quit()
+        except OptionException as problem:
+            _quit(problem)
+        except UnpickleError as problem:
+            _quit("Error loading checkpoint:", problem)
+        return op, checkpoint
