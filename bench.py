@@ -100,8 +100,8 @@ def main():
     table = libkernel.getProfile()
     libkernel.setProfile("")
     # counters that ride in the same dict are not kernels
-    counters = dict((k, prof.pop(k)) for k in list(prof) if k.startswith(("dp/", "net/step_graph")))
-    for k in [k for k in table if k.startswith(("dp/", "net/step_graph"))]:
+    counters = dict((k, prof.pop(k)) for k in list(prof) if k.startswith(("dp/", "net/step_")))
+    for k in [k for k in table if k.startswith(("dp/", "net/step_"))]:
         table.pop(k)
 
     if rank != 0:

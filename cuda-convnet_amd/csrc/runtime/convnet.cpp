@@ -347,6 +347,15 @@ void ConvNet::initDevice() {
     size_t split = 0;
     for (Layer* l : _layers) split = std::max(split, l->splitWorkspaceBytes(_dp->getMinibatchSize()));
     RT_MC(mc_reserve_conv_split_workspace(split, ST()));
+    // MC_NO_STEP_FORK=1: every step on one stream.  MC_STEP_FORK=graph: captured steps fork too (measured slower, see below).
+    const char* fork = getenv("MC_STEP_FORK");
+    _forkEager = getenv("MC_NO_STEP_FORK") == nullptr;
+    _forkGraph = _forkEager && fork && strstr(fork, "graph");
+    if (_forkEager || _forkGraph) {
+        RT_HIP(hipStreamCreateWithFlags(&_branchStream, hipStreamNonBlocking));
+        RT_HIP(hipEventCreateWithFlags(&_forkEvent, hipEventDisableTiming));
+        RT_HIP(hipEventCreateWithFlags(&_joinEvent, hipEventDisableTiming));
+    }
 }
 
 void ConvNet::run() {
@@ -422,6 +431,18 @@ void ConvNet::releaseHost() {
 }
 
 float* ConvNet::workspace(size_t bytes) {
+    if (_onBranch) {
+        if (bytes > _branchWorkspaceBytes) {
+            if (_capturing) throw std::runtime_error("weight-gradient branch needs a larger workspace than the eager steps did");
+            if (_branchWorkspace) {
+                RT_HIP(hipStreamSynchronize(_branchStream));
+                RT_HIP(hipFree(_branchWorkspace));
+            }
+            _branchWorkspaceBytes = (bytes + (4u << 20)) / (4u << 20) * (4u << 20);
+            RT_HIP(hipMalloc(reinterpret_cast<void**>(&_branchWorkspace), _branchWorkspaceBytes));
+        }
+        return _branchWorkspace;
+    }
     if (bytes > _workspaceBytes) {
         if (_workspace) {
             RT_HIP(hipStreamSynchronize(_stream));
@@ -460,10 +481,31 @@ void ConvNet::fprop(int miniIdx, PASS_TYPE passType) {
     fprop(passType);
 }
 
+void ConvNet::beginWeightGradBranch() {
+    RT_HIP(hipEventRecord(_forkEvent, _stream));
+    RT_HIP(hipStreamWaitEvent(_branchStream, _forkEvent, 0));
+    setComputeStream(_branchStream);
+    _onBranch = _branchOpen = true;
+}
+
+void ConvNet::endWeightGradBranch() {
+    setComputeStream(_stream);
+    _onBranch = false;
+}
+
+void ConvNet::joinWeightGradBranch() {
+    endWeightGradBranch();
+    if (!_branchOpen) return;
+    _branchOpen = false;
+    RT_HIP(hipEventRecord(_joinEvent, _branchStream));
+    RT_HIP(hipStreamWaitEvent(_stream, _joinEvent, 0));
+}
+
 void ConvNet::bprop(PASS_TYPE passType) {
     _buckets.beginStep();
     for (CostLayer* c : _costs) c->bprop(passType);
     reset();
+    if (_branchOpen) joinWeightGradBranch();   // the update (and whoever reads gradients next) waits for the branch
     if (_comm.active() && passType == PASS_TRAIN) {
         // whatever has not been sent yet goes now; the update then waits for the side stream
         size_t lo, hi;
@@ -477,7 +519,9 @@ void ConvNet::bprop(PASS_TYPE passType) {
 void ConvNet::gradientReady(Weights& w) {
     if (!_comm.active() || w.arenaIndex() < 0) return;
     size_t lo, hi;
-    if (_buckets.arrived((size_t)w.arenaIndex(), &lo, &hi)) _comm.allReduceAsync(_arenaGrad + lo, hi - lo, _stream);
+    // (the producer is the stream the gradient was just queued on: the weight-gradient branch when a step forks; a bucket
+    // may also hold tensors queued earlier on that same branch, and the branch runs in order)
+    if (_buckets.arrived((size_t)w.arenaIndex(), &lo, &hi)) _comm.allReduceAsync(_arenaGrad + lo, hi - lo, computeStream());
 }
 
 // One launch updates every tensor (spans of <= 4096 elements, built once); tensors that do not
@@ -564,6 +608,19 @@ void ConvNet::beginBatchCosts() {
 // Whatever differs from step to step stays outside the graph: the minibatch is staged into fixed matrices before the
 // launch, and the costs go to a fixed slot that the graph adds to a running total (read once per batch).
 // MC_NO_STEP_GRAPH=1 keeps every step eager.
+//
+// Eager steps (nets with dropout, data-parallel runs, profiled runs) fork instead: a layer's weight and bias gradient and
+// the rest of back-propagation below it read the same gradient matrix and write disjoint ones, so the weight-gradient
+// products run on a second stream (WeightLayer::bpropCommon forks it off the main stream with an event, ConvNet::bprop
+// joins it before the update; its split-K workspace is its own).  The k-contiguous weight gradients keep one workgroup per
+// CU waiting on its loads and the backward-data products fill the matrix pipe, so the two overlap well: NIN 1.914 -> 1.852
+// ms/step, imagenet-224 6.17 -> 5.87.  A step forks once its shape has run twice without allocating (every matrix sized,
+// contraction tiles tuned on an undisturbed stream) and never while every launch is being timed (setProfile("*")).
+// Results are bit-identical: the same kernels write the same buffers in the same order per buffer
+// (test_forked_steps_equal_single_stream_steps).  Captured steps do NOT fork by default: as branches of a HIP graph the same
+// split costs more in cross-branch dependencies than it gains on these small nets (layers-80sec 0.297 -> 0.325 ms/step), although
+// two such products issued on two plain streams do overlap (tools/overlap_probe.py: 49 -> 35 us per pair).
+// MC_NO_STEP_FORK=1 keeps every step on one stream.
 // ------------------------------------------------------------------------------------------
 bool ConvNet::stepGraphsAllowed() const {
     static const bool off = getenv("MC_NO_STEP_GRAPH") != nullptr;
@@ -579,6 +636,12 @@ void ConvNet::eagerStep(DevMatV& mb, int cases) {
 
 bool ConvNet::captureStep(StepGraph& g, DevMatV& mb) {
     hipGraph_t graph = nullptr;
+    if (_forkGraph && _branchWorkspaceBytes < _workspaceBytes) {   // as large as anything the eager steps asked for
+        if (_branchWorkspace) RT_HIP(hipFree(_branchWorkspace));
+        _branchWorkspaceBytes = _workspaceBytes;
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&_branchWorkspace), _branchWorkspaceBytes));
+    }
+    _forkThisStep = _forkGraph;
     bool ok = hipStreamBeginCapture(_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
     if (ok) {
         _capturing = true;
@@ -595,6 +658,10 @@ bool ConvNet::captureStep(StepGraph& g, DevMatV& mb) {
             ok = false;
             g.why = e.what();
         }
+        if (_branchOpen || _onBranch) {   // an exception left the branch open: join it so that the capture can end
+            try { joinWeightGradBranch(); } catch (std::exception&) { endWeightGradBranch(); _branchOpen = false; }
+        }
+        _forkThisStep = false;
         (void)mc_set_autotune(1);
         _capturing = false;
         if (hipStreamEndCapture(_stream, &graph) != hipSuccess || !graph) ok = false;
@@ -641,7 +708,18 @@ void ConvNet::trainStep(int miniIdx) {
         }
     }
     const unsigned long long draws = randDraws();
-    eagerStep(mb, cases);
+    // an eager step forks once its shape has run twice without allocating (matrices sized, contraction tiles tuned)
+    _forkThisStep = _forkEager && g.eagerRuns >= 2 && g.allocStamp == stamp && !_conserveMem && !profileEveryLaunch();
+    try {
+        eagerStep(mb, cases);
+    } catch (...) {
+        if (_branchOpen || _onBranch) { endWeightGradBranch(); _branchOpen = false; }
+        _forkThisStep = false;
+        throw;
+    }
+    _forkedSteps += _forkThisStep;
+    _forkThisStep = false;
+    g.allocStamp = DeviceAllocator::get().allocations();
     if (randDraws() != draws) _stochastic = true;   // dropout & co. take new random numbers every step
     g.eagerRuns++;
 }

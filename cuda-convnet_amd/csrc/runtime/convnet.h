@@ -156,6 +156,7 @@ public:
     bool capturing() const { return _capturing; }
     void trainStep(int miniIdx);   // fprop + costs + bprop + update of one minibatch, eager or as a replayed graph
     long stepGraphReplays() const { return _graphReplays; }
+    long forkedSteps() const { return _forkedSteps; }   // eager training steps whose weight gradients ran on the second stream
     void endMinibatchCosts(int numCases);
     Cost* collectCosts();
     double getCostValue();   // synchronous, last minibatch only (grad check)
@@ -167,6 +168,13 @@ public:
     void registerWeights(Weights* w) { _allWeights.push_back(w); }
     void gradientReady(Weights& w);           // called from WeightLayer::bpropCommon
     float* workspace(size_t bytes);
+    // Weight-gradient branch of a training step: between beginWeightGradBranch() and endWeightGradBranch() the thread's
+    // compute stream is a second stream that has waited for everything queued so far; joinWeightGradBranch() makes the
+    // main stream wait for it (ConvNet::bprop, before the update).  See "One training step" in convnet.cpp.
+    bool forksWeightGrads() const { return _forkThisStep; }
+    void beginWeightGradBranch();
+    void endWeightGradBranch();
+    void joinWeightGradBranch();
     // the 1/N of the gradient scale: the cases of the GLOBAL minibatch (all ranks).  Ranks hold equal shares except in a ragged
     // tail, where the driver hands the true global count down (startBatch's third argument); see dp.shard_columns.
     int gradScaleCases(int localCases) const { return _globalMinibatchCases > 0 ? _globalMinibatchCases : localCases * _comm.world(); }
@@ -196,6 +204,7 @@ private:
     bool _capturing = false, _stochastic = false, _conserveMem = false;
     int _graphCases = 0;                    // cases of this batch that ran as replayed graphs
     long _graphReplays = 0;                 // steps replayed since initModel
+    long _forkedSteps = 0;
 
     void run();
     void initDevice();
@@ -221,6 +230,12 @@ private:
     int _numSpans = 0;
     float* _workspace = nullptr;
     size_t _workspaceBytes = 0;
+    hipStream_t _branchStream = nullptr;   // the weight-gradient branch of a step
+    hipEvent_t _forkEvent = nullptr, _joinEvent = nullptr;
+    float* _branchWorkspace = nullptr;     // its own split-K workspace: both branches may hold slabs at once
+    size_t _branchWorkspaceBytes = 0;
+    bool _forkEager = false, _forkGraph = false;   // MC_STEP_FORK
+    bool _forkThisStep = false, _onBranch = false, _branchOpen = false;
     GradComm _comm;
     int _slot = 0;
     std::vector<int> _slotCases;

@@ -33,6 +33,7 @@ void profileSetFilter(const char* filter) {
 }
 
 bool profileOn() { return g_profOn; }
+bool profileEveryLaunch() { return g_profOn && g_profFilter == "*"; }
 
 void profileSetLayer(const char* layerName) {
     if (g_profOn) g_profLayer = layerName ? layerName : "";

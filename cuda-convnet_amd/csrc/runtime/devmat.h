@@ -41,6 +41,7 @@ private:
 };
 void profileSetFilter(const char* filter);            // NULL / "" switches profiling off
 bool profileOn();
+bool profileEveryLaunch();                            // the filter is "*": launches are timed one by one, steps stay on one stream
 void profileSetLayer(const char* layerName);
 void profileSetPhase(const char* phase);              // "fwd" / "wgrad" / "bwd": part of the key
 void profileReport(std::map<std::string, std::pair<long, double>>& out, bool reset);

@@ -81,6 +81,7 @@ void Layer::bprop(DevMat& v, PASS_TYPE passType) {
     profileSetPhase("wgrad");
     bpropCommon(v, passType);
     profileSetPhase("bwd");
+    if (isGradProducer() && bpropOverwritesActs() && _convNet->forksWeightGrads()) _convNet->joinWeightGradBranch();
     if (isGradProducer()) {
         auto send = [&](int i) {
             Layer* p = _prev[i];
@@ -399,6 +400,16 @@ void WeightLayer::bpropCommon(DevMat& v, PASS_TYPE passType) {
     static const bool noFuse = getenv("MC_NO_FUSED_BIAS") != nullptr;
     const bool biases = _biases->getEps() > 0;
     const bool fused = biases && !noFuse && fusesBiasGrad() && _weights.getSize() > 0 && _weights[0].getEps() > 0;
+    // When the step forks (convnet.cpp, "One training step") these products go to the weight-gradient branch: they read v and
+    // the inputs, which nothing below this layer writes (not so if this layer's gradient were written in place).
+    struct Branch {
+        ConvNet* net;
+        explicit Branch(ConvNet* n) : net(n) { if (net) net->beginWeightGradBranch(); }
+        ~Branch() { if (net) net->endWeightGradBranch(); }
+    } branch(passType == PASS_TRAIN && _convNet->forksWeightGrads() && _actsGradTarget < 0 ? _convNet : nullptr);
+    // (a layer that cannot fork queues on the main stream what earlier layers queued on the branch: gradient buckets and
+    // shared tensors assume one producer stream at a time, so the branch is joined first)
+    if (!branch.net && _convNet->forksWeightGrads()) _convNet->joinWeightGradBranch();
     if (biases && !fused) {
         bpropBiases(v, passType);
         _convNet->gradientReady(*_biases);

@@ -157,6 +157,10 @@ public:
     // bytes of library-side split-K workspace this layer's forward / backward-data calls need at `numCases` (0: none); the
     // net reserves the largest at initModel so that no training step allocates (mc_reserve_conv_split_workspace)
     virtual size_t splitWorkspaceBytes(int numCases) const { return 0; }
+    // true when bpropActs uses this layer's OUTPUT matrix as scratch (the normalisation layers, as in the reference): whoever
+    // still reads those outputs on another stream -- the weight gradients of the layers above, when the step forks -- has to
+    // be waited for first (Layer::bprop)
+    virtual bool bpropOverwritesActs() const { return false; }
 
     // weight layers override these
     virtual void updateWeights() {}
@@ -446,6 +450,7 @@ protected:
 class ResponseNormLayer : public Layer {
 public:
     ResponseNormLayer(ConvNet* convNet, PyObject* paramsDict);
+    bool bpropOverwritesActs() const override { return true; }   // mc_conv_response_norm*_undo, all of this family
 
 protected:
     void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;

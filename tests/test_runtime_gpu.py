@@ -155,6 +155,20 @@ def test_captured_steps_equal_eager_steps(net_name, cases, mini):
         np.testing.assert_allclose(got["cost:" + k][0], v[0], rtol=2e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("net_name,cases,mini", [("nin-tiny", 6 * 32 + 7, 32), ("conv-local", 5 * 16, 16), ("example-small", 4 * 16 + 3, 16)])
+def test_forked_steps_equal_single_stream_steps(net_name, cases, mini):
+    """Eager training steps run their weight-gradient products on a second stream from the third minibatch of a shape on
+    (ConvNet::trainStep / WeightLayer::bpropCommon).  Same kernels, same buffers, same order per buffer: everything the batch
+    leaves behind is bit-identical to a run that keeps every step on one stream (MC_NO_STEP_FORK=1).  Graphs are off in both
+    runs so that every step is an eager one (nin-tiny has dropout and would stay eager anyway)."""
+    got, _ = run_child(net=net_name, cases=cases, mini=mini, init_w=0.05, _env={"MC_NO_STEP_GRAPH": "1"})
+    ref, _ = run_child(net=net_name, cases=cases, mini=mini, init_w=0.05, _env={"MC_NO_STEP_GRAPH": "1", "MC_NO_STEP_FORK": "1"})
+    assert int(got["forkedSteps"]) == cases // mini - 2 and int(ref["forkedSteps"]) == 0
+    for k in ref:
+        if k.startswith("cost:") or k[0] in "WB":
+            assert np.array_equal(got[k], ref[k]), k
+
+
 def test_test_pass_costs_and_no_update():
     got, _ = run_child(net="nin-tiny", cases=150, mini=64, test=1, acts="probs")
     net, layers, costs = oracle_run("nin-tiny", 150, 64, test=True)
