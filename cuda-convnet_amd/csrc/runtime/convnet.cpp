@@ -607,9 +607,13 @@ void ConvNet::beginBatchCosts() {
 // contraction autotuner settle) and replayed from then on: one launch per step plus the staging copies of the minibatch.
 // Whatever differs from step to step stays outside the graph: the minibatch is staged into fixed matrices before the
 // launch, and the costs go to a fixed slot that the graph adds to a running total (read once per batch).
-// MC_NO_STEP_GRAPH=1 keeps every step eager.
+// Whether replaying pays is measured, not assumed: the four steps after the capture alternate between the graph and an eager
+// step, timed with events, and the faster way is kept for the shape (both are training steps with bit-identical results,
+// so nothing is run twice).  The graph wins where the host cannot keep up with ~35 launches of 3-30 us; eager steps win on
+// larger nets because they fork (next paragraph): imagenet-224 6.16 ms replayed, 5.97 eager; conv-local 0.475 / 0.452.
+// MC_NO_STEP_GRAPH=1 keeps every step eager, MC_STEP_GRAPH=1 replays whenever a graph exists.
 //
-// Eager steps (nets with dropout, data-parallel runs, profiled runs) fork instead: a layer's weight and bias gradient and
+// Eager steps fork: a layer's weight and bias gradient and
 // the rest of back-propagation below it read the same gradient matrix and write disjoint ones, so the weight-gradient
 // products run on a second stream (WeightLayer::bpropCommon forks it off the main stream with an event, ConvNet::bprop
 // joins it before the update; its split-K workspace is its own).  The k-contiguous weight gradients keep one workgroup per
@@ -679,34 +683,7 @@ bool ConvNet::captureStep(StepGraph& g, DevMatV& mb) {
     return ok;
 }
 
-void ConvNet::trainStep(int miniIdx) {
-    const int cases = _dp->getNumCasesInMinibatch(miniIdx);
-    DevMatV& mb = _dp->getMinibatch(miniIdx);   // staged into the provider's fixed matrices: same addresses every step
-    StepGraph& g = _stepGraphs[cases];
-    const unsigned long long stamp = DeviceAllocator::get().allocations();
-    if (g.exec && g.allocStamp != stamp) {   // some matrix has moved since the capture: the graph's addresses are stale
-        (void)hipGraphExecDestroy(g.exec);
-        g.exec = nullptr;
-        g.eagerRuns = 1;
-    }
-    if (stepGraphsAllowed() && !g.bad) {
-        if (!g.exec && g.eagerRuns >= 2) {
-            captureStep(g, mb);   // nothing runs during the capture
-            g.allocStamp = DeviceAllocator::get().allocations();
-            if (g.exec && g.allocStamp != stamp) {   // the step still allocates: not a shape to replay yet
-                (void)hipGraphExecDestroy(g.exec);
-                g.exec = nullptr;
-                g.eagerRuns = 1;
-            }
-        }
-        if (g.exec) {
-            RT_HIP(hipGraphLaunch(g.exec, _stream));
-            _graphCases += cases;
-            _graphReplays++;
-            for (Weights* w : _allWeights) w->markUpdated();
-            return;
-        }
-    }
+void ConvNet::runEagerStep(StepGraph& g, DevMatV& mb, int cases, unsigned long long stamp) {
     const unsigned long long draws = randDraws();
     // an eager step forks once its shape has run twice without allocating (matrices sized, contraction tiles tuned)
     _forkThisStep = _forkEager && g.eagerRuns >= 2 && g.allocStamp == stamp && !_conserveMem && !profileEveryLaunch();
@@ -722,6 +699,69 @@ void ConvNet::trainStep(int miniIdx) {
     g.allocStamp = DeviceAllocator::get().allocations();
     if (randDraws() != draws) _stochastic = true;   // dropout & co. take new random numbers every step
     g.eagerRuns++;
+}
+
+void ConvNet::trainStep(int miniIdx) {
+    const int cases = _dp->getNumCasesInMinibatch(miniIdx);
+    DevMatV& mb = _dp->getMinibatch(miniIdx);   // staged into the provider's fixed matrices: same addresses every step
+    StepGraph& g = _stepGraphs[cases];
+    const unsigned long long stamp = DeviceAllocator::get().allocations();
+    if (g.exec && g.allocStamp != stamp) {   // some matrix has moved since the capture: the graph's addresses are stale
+        (void)hipGraphExecDestroy(g.exec);
+        g.exec = nullptr;
+        g.eagerRuns = 1;
+        g.mode = StepGraph::UNDECIDED;
+        g.trials = 0;
+        g.graphMs = g.eagerMs = 1e30f;
+    }
+    // MC_STEP_GRAPH=1: replay whenever a graph exists (no trial); MC_NO_STEP_GRAPH=1: never capture
+    static const bool forceGraph = getenv("MC_STEP_GRAPH") != nullptr;
+    bool replay = false, trial = false;
+    if (stepGraphsAllowed() && !g.bad) {
+        if (!g.exec && g.eagerRuns >= 2) {
+            captureStep(g, mb);   // nothing runs during the capture
+            g.allocStamp = DeviceAllocator::get().allocations();
+            if (g.exec && g.allocStamp != stamp) {   // the step still allocates: not a shape to replay yet
+                (void)hipGraphExecDestroy(g.exec);
+                g.exec = nullptr;
+                g.eagerRuns = 1;
+            }
+        }
+        if (g.exec) {
+            if (forceGraph) g.mode = StepGraph::GRAPH;
+            trial = g.mode == StepGraph::UNDECIDED;
+            replay = trial ? g.trials % 2 == 0 : g.mode == StepGraph::GRAPH;
+        }
+    }
+    if (trial) {
+        if (!_trialBegin) {
+            RT_HIP(hipEventCreate(&_trialBegin));
+            RT_HIP(hipEventCreate(&_trialEnd));
+        }
+        RT_HIP(hipEventRecord(_trialBegin, _stream));
+    }
+    if (replay) {
+        RT_HIP(hipGraphLaunch(g.exec, _stream));
+        _graphCases += cases;
+        _graphReplays++;
+        for (Weights* w : _allWeights) w->markUpdated();
+    } else {
+        runEagerStep(g, mb, cases, stamp);
+    }
+    if (trial) {   // two timed steps each way (a step is a step: both update the weights), then the faster way for good
+        float ms = 0.f;
+        RT_HIP(hipEventRecord(_trialEnd, _stream));
+        RT_HIP(hipEventSynchronize(_trialEnd));
+        RT_HIP(hipEventElapsedTime(&ms, _trialBegin, _trialEnd));
+        float& best = replay ? g.graphMs : g.eagerMs;
+        best = std::min(best, ms);
+        if (++g.trials == 4) {
+            g.mode = g.graphMs <= g.eagerMs ? StepGraph::GRAPH : StepGraph::EAGER;
+            if (getenv("MC_STEP_GRAPH_VERBOSE"))
+                fprintf(stderr, "[libkernel] steps of %d cases: replayed graph %.3f ms, eager %.3f ms -> %s\n", cases, g.graphMs, g.eagerMs,
+                        g.mode == StepGraph::GRAPH ? "graph" : "eager");
+        }
+    }
 }
 
 double ConvNet::getCostValue() {

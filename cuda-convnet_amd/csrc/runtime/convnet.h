@@ -196,10 +196,16 @@ private:
         unsigned long long allocStamp = 0;   // DeviceAllocator::allocations() when captured
         bool bad = false;      // a capture failed: steps of this shape stay eager
         std::string why;
+        enum Mode { UNDECIDED, GRAPH, EAGER };   // which way steps of this shape run once a graph exists (trainStep's trial)
+        Mode mode = UNDECIDED;
+        int trials = 0;
+        float graphMs = 1e30f, eagerMs = 1e30f;
     };
     bool stepGraphsAllowed() const;
     void eagerStep(DevMatV& mb, int cases);
     bool captureStep(StepGraph& g, DevMatV& mb);
+    void runEagerStep(StepGraph& g, DevMatV& mb, int cases, unsigned long long stamp);
+    hipEvent_t _trialBegin = nullptr, _trialEnd = nullptr;
     std::map<int, StepGraph> _stepGraphs;   // by cases in the minibatch
     bool _capturing = false, _stochastic = false, _conserveMem = false;
     int _graphCases = 0;                    // cases of this batch that ran as replayed graphs

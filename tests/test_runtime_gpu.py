@@ -140,7 +140,7 @@ def test_captured_steps_equal_eager_steps(net_name, cases, mini):
     (ConvNet::trainStep).  Same kernels, same arguments: weights, increments and biases after the batch are bit-identical to
     an all-eager run (MC_NO_STEP_GRAPH=1), the costs agree (device-side double accumulation vs host-side), and the ragged tail
     -- a shape seen once -- runs eagerly in both.  Also against the oracle, like every other whole-step test."""
-    got, _ = run_child(net=net_name, cases=cases, mini=mini, init_w=0.05)
+    got, _ = run_child(net=net_name, cases=cases, mini=mini, init_w=0.05, _env={"MC_STEP_GRAPH": "1"})   # replay, no timing trial
     ref, _ = run_child(net=net_name, cases=cases, mini=mini, init_w=0.05, _env={"MC_NO_STEP_GRAPH": "1"})
     full = cases // mini
     assert int(got["graphReplays"]) == full - 2 and int(ref["graphReplays"]) == 0
@@ -153,6 +153,23 @@ def test_captured_steps_equal_eager_steps(net_name, cases, mini):
     net, layers, costs = oracle_run(net_name, cases, mini, init_w=0.05)
     for k, v in costs.items():
         np.testing.assert_allclose(got["cost:" + k][0], v[0], rtol=2e-4, atol=1e-3)
+
+
+def test_graph_or_eager_trial_changes_no_result():
+    """By default the four steps after a capture alternate between the replayed graph and an eager (forking) step, timed, and the
+    faster way is kept (ConvNet::trainStep).  Whichever way wins, and through the trial itself, the batch leaves behind exactly
+    what an all-eager single-stream run leaves."""
+    cases, mini = 9 * 32 + 5, 32
+    got, _ = run_child(net="80sec", cases=cases, mini=mini, init_w=0.05)
+    ref, _ = run_child(net="80sec", cases=cases, mini=mini, init_w=0.05, _env={"MC_NO_STEP_GRAPH": "1", "MC_NO_STEP_FORK": "1"})
+    replays, forked = int(got["graphReplays"]), int(got["forkedSteps"])
+    assert replays >= 2 and forked >= 2 and replays + forked == cases // mini - 2     # two trial steps each way, then one of the two
+    assert int(got["numCases"]) == int(ref["numCases"]) == cases
+    for k in ref:
+        if k.startswith("cost:"):
+            np.testing.assert_allclose(got[k], ref[k], rtol=1e-12, atol=1e-9)
+        elif k[0] in "WB":
+            assert np.array_equal(got[k], ref[k]), k
 
 
 @pytest.mark.parametrize("net_name,cases,mini", [("nin-tiny", 6 * 32 + 7, 32), ("conv-local", 5 * 16, 16), ("example-small", 4 * 16 + 3, 16)])
