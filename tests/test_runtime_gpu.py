@@ -275,11 +275,15 @@ def test_counter_dropout_equals_stored_masks():
     assert not np.array_equal(a["W:conv2:0"], c["W:conv2:0"])        # another seed is another mask
 
 
-def test_single_rank_rccl_path_is_identity():
+@pytest.mark.parametrize("net_name,cases,mini", [("nin-tiny", 128, 64), ("nin-tiny", 6 * 32, 32), ("conv-local", 5 * 16, 16)])
+def test_single_rank_rccl_path_is_identity(net_name, cases, mini):
     """world_size 1 through the real RCCL all-reduce / side-stream / event path gives the same
-    weights as the path without a communicator."""
-    a, _ = run_child(net="nin-tiny", cases=128, mini=64)
-    b, _ = run_child(net="nin-tiny", cases=128, mini=64, single_rank_comm=1)
+    weights as the path without a communicator.  The longer runs reach the steps that produce their weight gradients on the
+    branch stream (third minibatch of a shape on), so the buckets' all-reduces are ordered behind that stream; conv-local's
+    unshared layers are large enough for buckets to go out in the middle of back-propagation."""
+    a, _ = run_child(net=net_name, cases=cases, mini=mini, _env={"MC_NO_STEP_GRAPH": "1"})
+    b, _ = run_child(net=net_name, cases=cases, mini=mini, single_rank_comm=1)
+    assert int(b["forkedSteps"]) == max(0, cases // mini - 2) and int(b["graphReplays"]) == 0
     for k in a:
         if k.startswith(("W:", "B:")):
             np.testing.assert_array_equal(a[k], b[k])
