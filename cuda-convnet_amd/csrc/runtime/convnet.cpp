@@ -32,6 +32,27 @@ std::atomic<unsigned long long> g_randDraws{0};   // calls that took (or injecte
 
 unsigned long long randDraws() { return g_randDraws.load(std::memory_order_relaxed); }
 
+// A dry run (ConvNet::warmUp) must leave the random stream where it found it: the hold sets injected masks aside (the dry
+// run draws from the counter-based stream instead) and its destructor puts masks, stream position and draw count back.
+namespace {
+struct RandHold {
+    std::deque<std::vector<float>> injected;
+    unsigned long long offset, draws;
+    RandHold() {
+        std::lock_guard<std::mutex> g(g_randMutex);
+        injected.swap(g_injected);
+        offset = g_offset;
+        draws = g_randDraws.load(std::memory_order_relaxed);
+    }
+    ~RandHold() {
+        std::lock_guard<std::mutex> g(g_randMutex);
+        injected.swap(g_injected);
+        g_offset = offset;
+        g_randDraws.store(draws, std::memory_order_relaxed);
+    }
+};
+}  // namespace
+
 void setRandSeed(unsigned long long seed) {
     std::lock_guard<std::mutex> g(g_randMutex);
     g_seed = seed;
@@ -506,7 +527,7 @@ void ConvNet::bprop(PASS_TYPE passType) {
     for (CostLayer* c : _costs) c->bprop(passType);
     reset();
     if (_branchOpen) joinWeightGradBranch();   // the update (and whoever reads gradients next) waits for the branch
-    if (_comm.active() && passType == PASS_TRAIN) {
+    if (_comm.active() && passType == PASS_TRAIN && !_warming) {
         // whatever has not been sent yet goes now; the update then waits for the side stream
         size_t lo, hi;
         if (_buckets.finish(&lo, &hi)) _comm.allReduceAsync(_arenaGrad + lo, hi - lo, _stream);
@@ -517,7 +538,7 @@ void ConvNet::bprop(PASS_TYPE passType) {
 // A tensor's gradient is complete once every layer that adds into it has queued its product; complete tensors are reduced
 // on the side stream in buckets of >= kBucketElems while the rest of back-propagation runs (buckets.h has the rules).
 void ConvNet::gradientReady(Weights& w) {
-    if (!_comm.active() || w.arenaIndex() < 0) return;
+    if (!_comm.active() || _warming || w.arenaIndex() < 0) return;
     size_t lo, hi;
     // (the producer is the stream the gradient was just queued on: the weight-gradient branch when a step forks; a bucket
     // may also hold tensors queued earlier on that same branch, and the branch runs in order)
@@ -681,6 +702,36 @@ bool ConvNet::captureStep(StepGraph& g, DevMatV& mb) {
         if (getenv("MC_STEP_GRAPH_VERBOSE")) fprintf(stderr, "[libkernel] step graph not captured (%s): steps of this shape stay eager\n", g.why.c_str());
     }
     return ok;
+}
+
+// Dry run of one training step per minibatch shape of a batch, before its first real step (TrainingWorker / ResidentWorker):
+// forward and backward on the shape's first minibatch, no update.  It sizes every matrix and lets the contraction autotuner
+// time its candidates for the full AND the ragged-tail shape up front, so that no step of the batch carries timing trials or
+// allocations.  Nothing it does survives: gradients are overwritten by the next step (accumulation flags cleared), the cost
+// slot is cleared, the random stream and injected masks are put back, nothing is all-reduced.  MC_NO_WARMUP=1 skips it.
+void ConvNet::warmUpShapes() {
+    static const bool off = getenv("MC_NO_WARMUP") != nullptr;
+    if (off || profileOn()) return;
+    for (int i = 0; i < _dp->getNumMinibatches(); i++) {
+        StepGraph& g = _stepGraphs[_dp->getNumCasesInMinibatch(i)];
+        if (g.warmed || g.eagerRuns > 0) continue;
+        g.warmed = true;
+        RandHold hold;
+        _warming = true;
+        try {
+            fprop(i, PASS_TRAIN);
+            bprop(PASS_TRAIN);
+        } catch (...) {
+            _warming = false;
+            throw;
+        }
+        _warming = false;
+        _warmedShapes++;
+        for (Weights* w : _allWeights) w->markUpdated();
+        for (CostLayer* c : _costs)
+            if (c->deviceSlots())
+                RT_HIP(hipMemsetAsync(c->deviceSlots() + (size_t)_slot * c->numCostValues(), 0, sizeof(double) * c->numCostValues(), _stream));
+    }
 }
 
 void ConvNet::runEagerStep(StepGraph& g, DevMatV& mb, int cases, unsigned long long stamp) {
@@ -878,6 +929,7 @@ void TrainingWorker::run() {
             _convNet->fprop(i, PASS_TEST);
             _convNet->endMinibatchCosts(dp.getNumCasesInMinibatch(i));
         } else {
+            if (i == 0) _convNet->warmUpShapes();
             _convNet->trainStep(i);
         }
     }
@@ -891,6 +943,7 @@ void ResidentWorker::run() {
     DataProvider& dp = _convNet->getDataProvider();
     const int nmb = dp.getNumMinibatches();
     _convNet->beginBatchCosts();
+    if (!_test && _count > 0) _convNet->warmUpShapes();
     for (int k = 0; k < _count; k++) {
         const int i = (_first + k) % nmb;
         if (_test) {

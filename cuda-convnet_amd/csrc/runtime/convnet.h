@@ -154,8 +154,10 @@ public:
     void beginBatchCosts();
     // while a step is being captured into a graph the costs go to a fixed slot (CostLayer::GRAPH_SLOT)
     bool capturing() const { return _capturing; }
+    void warmUpShapes();           // dry run per minibatch shape of the current batch (sizes matrices, tunes tiles); see convnet.cpp
     void trainStep(int miniIdx);   // fprop + costs + bprop + update of one minibatch, eager or as a replayed graph
     long stepGraphReplays() const { return _graphReplays; }
+    long warmedShapes() const { return _warmedShapes; }   // minibatch shapes dry-run by warmUpShapes since initModel
     long forkedSteps() const { return _forkedSteps; }   // eager training steps whose weight gradients ran on the second stream
     void endMinibatchCosts(int numCases);
     Cost* collectCosts();
@@ -194,6 +196,7 @@ private:
         hipGraphExec_t exec = nullptr;
         int eagerRuns = 0;
         unsigned long long allocStamp = 0;   // DeviceAllocator::allocations() when captured
+        bool warmed = false;   // warmUpShapes has run this shape
         bool bad = false;      // a capture failed: steps of this shape stay eager
         std::string why;
         enum Mode { UNDECIDED, GRAPH, EAGER };   // which way steps of this shape run once a graph exists (trainStep's trial)
@@ -210,7 +213,7 @@ private:
     bool _capturing = false, _stochastic = false, _conserveMem = false;
     int _graphCases = 0;                    // cases of this batch that ran as replayed graphs
     long _graphReplays = 0;                 // steps replayed since initModel
-    long _forkedSteps = 0;
+    long _forkedSteps = 0, _warmedShapes = 0;
 
     void run();
     void initDevice();
@@ -242,6 +245,7 @@ private:
     size_t _branchWorkspaceBytes = 0;
     bool _forkEager = false, _forkGraph = false;   // MC_STEP_FORK
     bool _forkThisStep = false, _onBranch = false, _branchOpen = false;
+    bool _warming = false;
     GradComm _comm;
     int _slot = 0;
     std::vector<int> _slotCases;

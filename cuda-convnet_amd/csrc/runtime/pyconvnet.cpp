@@ -335,6 +335,7 @@ static PyObject* getProfile(PyObject*, PyObject*) {
     PyObject* ok = run_on_device([&] {
         profileReport(rep, true);
         rep["net/step_graph:replays"] = std::make_pair(model->stepGraphReplays(), 0.0);   // training steps replayed as HIP graphs so far
+        rep["net/step_warm:shapes"] = std::make_pair(model->warmedShapes(), 0.0);         // minibatch shapes dry-run before their first step
         rep["net/step_fork:steps"] = std::make_pair(model->forkedSteps(), 0.0);           // eager steps that ran their weight gradients on the second stream
         if (model->comm().active()) {
             const GradComm::Stats st = model->comm().takeStats();

@@ -155,6 +155,21 @@ def test_captured_steps_equal_eager_steps(net_name, cases, mini):
         np.testing.assert_allclose(got["cost:" + k][0], v[0], rtol=2e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("net_name,cases,mini", [("nin-tiny", 3 * 32 + 7, 32), ("example-small", 2 * 16 + 3, 16)])
+def test_warm_up_leaves_no_trace(net_name, cases, mini):
+    """Before the first training step of a batch the runtime dry-runs one forward + backward pass per minibatch shape (full and
+    ragged tail: ConvNet::warmUpShapes) so that matrices are sized and contraction tiles tuned outside the steps.  The dry run
+    must not move the random stream (nin-tiny draws dropout masks from it), leave gradients or costs behind, or touch weights:
+    the batch ends bit-identical to one without the dry run."""
+    got, _ = run_child(net=net_name, cases=cases, mini=mini, init_w=0.05, philox_seed=7)
+    ref, _ = run_child(net=net_name, cases=cases, mini=mini, init_w=0.05, philox_seed=7, _env={"MC_NO_WARMUP": "1"})
+    assert int(got["numCases"]) == int(ref["numCases"]) == cases
+    assert int(got["warmedShapes"]) == 2 and int(ref["warmedShapes"]) == 0     # the full shape and the tail
+    for k in ref:
+        if k.startswith("cost:") or k[0] in "WB":
+            assert np.array_equal(got[k], ref[k]), k
+
+
 def test_graph_or_eager_trial_changes_no_result():
     """By default the four steps after a capture alternate between the replayed graph and an eager (forking) step, timed, and the
     faster way is kept (ConvNet::trainStep).  Whichever way wins, and through the trial itself, the batch leaves behind exactly
