@@ -240,9 +240,14 @@ GradComm::~GradComm() {
     // the communicator lives for the life of the process, like the model (pyconvnet.cu:47)
 }
 
-void GradComm::allReduceAsync(float* p, size_t n, hipStream_t producer) {
+void GradComm::allReduceAsync(float* p, size_t n, hipStream_t producer, hipStream_t alsoAfter) {
     if (!_comm || n == 0) return;
-    // the side stream picks up after everything the compute stream has queued so far
+    // the side stream picks up after everything the producing stream has queued so far (and, when a step has gradients
+    // queued on two streams, after the other one too)
+    if (alsoAfter && alsoAfter != producer) {
+        RT_HIP(hipEventRecord(_ready, alsoAfter));
+        RT_HIP(hipStreamWaitEvent(_stream, _ready, 0));
+    }
     RT_HIP(hipEventRecord(_ready, producer));
     RT_HIP(hipStreamWaitEvent(_stream, _ready, 0));
     nccl_check(rccl().allReduce(p, p, n, kNcclFloat, kNcclSum, _comm, _stream), "ncclAllReduce");
@@ -542,7 +547,10 @@ void ConvNet::gradientReady(Weights& w) {
     size_t lo, hi;
     // (the producer is the stream the gradient was just queued on: the weight-gradient branch when a step forks; a bucket
     // may also hold tensors queued earlier on that same branch, and the branch runs in order)
-    if (_buckets.arrived((size_t)w.arenaIndex(), &lo, &hi)) _comm.allReduceAsync(_arenaGrad + lo, hi - lo, computeStream());
+    // (a first layer's gradient is queued on the main stream while the branch is open, see WeightLayer::bpropCommon: then
+    // the bucket may hold tensors of both streams and the all-reduce waits for both)
+    if (_buckets.arrived((size_t)w.arenaIndex(), &lo, &hi))
+        _comm.allReduceAsync(_arenaGrad + lo, hi - lo, computeStream(), _branchOpen ? _branchStream : nullptr);
 }
 
 // One launch updates every tensor (spans of <= 4096 elements, built once); tensors that do not

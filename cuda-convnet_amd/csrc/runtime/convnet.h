@@ -94,7 +94,7 @@ public:
     bool active() const { return _world > 1 || _forced; }
     int world() const { return _world; }
     int rank() const { return _rank; }
-    void allReduceAsync(float* p, size_t n, hipStream_t producer);   // sum, in place
+    void allReduceAsync(float* p, size_t n, hipStream_t producer, hipStream_t alsoAfter = nullptr);   // sum, in place
     void waitAll(hipStream_t consumer);
     void forceSingleRank(bool f) { _forced = f; }   // exercise the RCCL path with world == 1 (tests)
     // Counters since the last report: all-reduce calls and bytes, steps (waitAll calls), and the time the compute stream

@@ -401,15 +401,24 @@ void WeightLayer::bpropCommon(DevMat& v, PASS_TYPE passType) {
     const bool biases = _biases->getEps() > 0;
     const bool fused = biases && !noFuse && fusesBiasGrad() && _weights.getSize() > 0 && _weights[0].getEps() > 0;
     // When the step forks (convnet.cpp, "One training step") these products go to the weight-gradient branch: they read v and
-    // the inputs, which nothing below this layer writes (not so if this layer's gradient were written in place).
+    // the inputs, which nothing below this layer writes (not so if this layer's gradient were written in place).  A layer
+    // with nothing below it to overlap with (the first layer of a net: its input takes no gradient) stays on the main stream
+    // instead and runs beside whatever the branch still has queued -- unless it shares a weight tensor, whose other
+    // contributions are accumulated on the branch.
+    const bool forks = passType == PASS_TRAIN && _convNet->forksWeightGrads();
+    bool below = false, shares = false;
+    for (Layer* p : _prev) below |= p->isGradConsumer();
+    for (int i = 0; i < _weights.getSize(); i++) shares |= _weights[i].contributors() > 1;
+    const bool onBranch = forks && _actsGradTarget < 0 && (below || shares);
+    const bool besideBranch = forks && _actsGradTarget < 0 && !onBranch;
     struct Branch {
         ConvNet* net;
         explicit Branch(ConvNet* n) : net(n) { if (net) net->beginWeightGradBranch(); }
         ~Branch() { if (net) net->endWeightGradBranch(); }
-    } branch(passType == PASS_TRAIN && _convNet->forksWeightGrads() && _actsGradTarget < 0 ? _convNet : nullptr);
-    // (a layer that cannot fork queues on the main stream what earlier layers queued on the branch: gradient buckets and
-    // shared tensors assume one producer stream at a time, so the branch is joined first)
-    if (!branch.net && _convNet->forksWeightGrads()) _convNet->joinWeightGradBranch();
+    } branch(onBranch ? _convNet : nullptr);
+    // (a layer that cannot fork queues on the main stream what earlier layers queued on the branch: shared tensors assume one
+    // producer stream at a time, so the branch is joined first)
+    if (forks && !onBranch && !besideBranch) _convNet->joinWeightGradBranch();
     if (biases && !fused) {
         bpropBiases(v, passType);
         _convNet->gradientReady(*_biases);
