@@ -448,39 +448,74 @@ __global__ void __launch_bounds__(RED_T) k_softmax_logreg(const float* __restric
     __shared__ double shl[RED_T], shc[RED_T];
     double accL = 0.0, accC = 0.0;
     for (int n = threadIdx.x; n < numCases; n += RED_T) {
-        float mx = in[n];
-        for (int j = 1; j < numOut; ++j) mx = fmaxf(mx, in[(size_t)j * numCases + n]);
-        float sum = 0.f;
-        for (int j = 0; j < numOut; ++j) {
-            const float e = expf(in[(size_t)j * numCases + n] - mx);
-            probs[(size_t)j * numCases + n] = e;
-            sum += e;
-        }
-        float maxp = 0.f;
-        for (int j = 0; j < numOut; ++j) {
-            const float p = probs[(size_t)j * numCases + n] / sum;
-            probs[(size_t)j * numCases + n] = p;
-            maxp = j == 0 ? p : fmaxf(maxp, p);
-        }
+        // Every pass reads the inputs afresh (they stay in cache) and recomputes exp(x - max) instead of reading back what the
+        // pass before stored: the values are the same bits, and the loads of a pass are independent of each other, so a lane
+        // has several in flight instead of one store -> load round trip per class.
+        const float* col = in + n;
         const int label = (int)labels[n];
-        const float lp = probs[(size_t)label * numCases + n];
-        const float ll = logf(lp);
-        float cp = 0.f;
-        if (lp == maxp) {
-            int numMax = 0;
-            for (int j = 0; j < numOut; ++j) numMax += probs[(size_t)j * numCases + n] == maxp;
-            cp = 1.0f / (float)numMax;
+        float mx, sum = 0.f, maxp = 0.f, lp = 0.f, cp = 0.f;
+        if (numOut <= 16) {   // the ten-class nets: one pass of loads, the rest from registers (same operations in the same order)
+            float x[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) x[j] = j < numOut ? col[(size_t)j * numCases] : 0.f;
+            mx = x[0];
+#pragma unroll
+            for (int j = 1; j < 16; ++j) mx = j < numOut ? fmaxf(mx, x[j]) : mx;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                x[j] = expf(x[j] - mx);
+                sum = j < numOut ? sum + x[j] : sum;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                x[j] = x[j] / sum;
+                if (j < numOut) {
+                    const size_t idx = (size_t)j * numCases + n;
+                    probs[idx] = x[j];
+                    maxp = j == 0 ? x[j] : fmaxf(maxp, x[j]);
+                    lp = j == label ? x[j] : lp;
+                    if (grad) {
+                        const float v = coeff * ((label == j) - x[j]);
+                        grad[idx] = add ? grad[idx] + v : v;
+                    }
+                }
+            }
+            if (lp == maxp) {
+                int numMax = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) numMax += (j < numOut) & (x[j] == maxp);
+                cp = 1.0f / (float)numMax;
+            }
+        } else {
+            mx = col[0];
+#pragma unroll 8
+            for (int j = 1; j < numOut; ++j) mx = fmaxf(mx, col[(size_t)j * numCases]);
+#pragma unroll 8
+            for (int j = 0; j < numOut; ++j) sum += expf(col[(size_t)j * numCases] - mx);
+#pragma unroll 4
+            for (int j = 0; j < numOut; ++j) {
+                const size_t idx = (size_t)j * numCases + n;
+                const float p = expf(col[(size_t)j * numCases] - mx) / sum;
+                probs[idx] = p;
+                maxp = j == 0 ? p : fmaxf(maxp, p);
+                lp = j == label ? p : lp;
+                if (grad) {
+                    const float v = coeff * ((label == j) - p);
+                    grad[idx] = add ? grad[idx] + v : v;
+                }
+            }
+            if (lp == maxp) {
+                int numMax = 0;
+#pragma unroll 8
+                for (int j = 0; j < numOut; ++j) numMax += expf(col[(size_t)j * numCases] - mx) / sum == maxp;
+                cp = 1.0f / (float)numMax;
+            }
         }
+        const float ll = logf(lp);
         labelLogProbs[n] = ll;
         correctProbs[n] = cp;
         accL += (double)ll;
         accC += (double)cp;
-        if (grad)
-            for (int j = 0; j < numOut; ++j) {
-                const size_t idx = (size_t)j * numCases + n;
-                const float v = coeff * ((label == j) - probs[idx]);
-                grad[idx] = add ? grad[idx] + v : v;
-            }
     }
     shl[threadIdx.x] = accL;
     shc[threadIdx.x] = accC;
