@@ -22,4 +22,4 @@ libkernel.setProfile("*"); libkernel.startResident(0, 0, 5); libkernel.finishBat
 rows = sorted(((k, c / 5.0, ms / c) for k, (c, ms) in tab.items() if c and ms), key=lambda r: -r[1] * r[2])
 print("%s mb=%d: %.0f images/s, %.3f ms/step, cost/case %.4f; kernel time/step %.3f ms" % (net, mb, mb * steps / dt, dt / steps * 1e3, list(costs.values())[0][0] / n, sum(r[1] * r[2] for r in rows)))
 print("   steps replayed as graphs %d, eager steps with the weight-gradient branch %d" % (counters.get("net/step_graph:replays", 0), counters.get("net/step_fork:steps", 0)))
-for k, c, ms in rows[:10]: print("   %-52s x%.0f %8.4f ms" % (k, c, ms))
+for k, c, ms in rows[:int(sys.argv[4]) if len(sys.argv) > 4 else 10]: print("   %-52s x%.0f %8.4f ms" % (k, c, ms))
