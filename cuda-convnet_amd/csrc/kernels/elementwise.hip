@@ -382,6 +382,108 @@ __global__ void k_softmax(const float* __restrict__ in, float* out, int numCases
     }
     for (int j = 0; j < numOut; ++j) out[(size_t)j * numCases + n] = out[(size_t)j * numCases + n] / sum;
 }
+// ---- wide classifiers (>= 64 classes) -------------------------------------------------------------------
+// One lane walking all classes of a case is right for ten classes and 385 us for a thousand.  Here a workgroup takes four
+// neighbouring cases (one float4 per class row) and its 256 lanes take the classes 256 apart; maxima and sums are combined
+// in a fixed tree, so results are deterministic (the order of the additions differs from the one-lane kernels': the two
+// families agree to rounding, not bit for bit, which is why a given class count always takes the same family).
+constexpr int WIDE_T = 256;
+__device__ __forceinline__ float4 wide_reduce(float4 v, float4* sh, bool isMax) {
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = WIDE_T / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            const float4 a = sh[threadIdx.x], b = sh[threadIdx.x + s];
+            sh[threadIdx.x] = isMax ? make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w))
+                                    : make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        }
+        __syncthreads();
+    }
+    const float4 r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(WIDE_T) k_softmax_wide(const float* in, float* out, int numCases, int numOut) {
+    __shared__ float4 sh[WIDE_T];
+    const size_t n = (size_t)blockIdx.x * 4;
+    const float4* src = reinterpret_cast<const float4*>(in + n);
+    const size_t rowStride = (size_t)numCases / 4;
+    float4 mx = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f);
+    for (int j = threadIdx.x; j < numOut; j += WIDE_T) {
+        const float4 x = src[j * rowStride];
+        mx = make_float4(fmaxf(mx.x, x.x), fmaxf(mx.y, x.y), fmaxf(mx.z, x.z), fmaxf(mx.w, x.w));
+    }
+    mx = wide_reduce(mx, sh, true);
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = threadIdx.x; j < numOut; j += WIDE_T) {
+        const float4 x = src[j * rowStride];
+        sum.x += expf(x.x - mx.x); sum.y += expf(x.y - mx.y); sum.z += expf(x.z - mx.z); sum.w += expf(x.w - mx.w);
+    }
+    sum = wide_reduce(sum, sh, false);
+    float4* dst = reinterpret_cast<float4*>(out + n);   // (out may be in: every element is read and written by one lane, reads first)
+    for (int j = threadIdx.x; j < numOut; j += WIDE_T) {
+        const float4 x = src[j * rowStride];
+        dst[j * rowStride] = make_float4(expf(x.x - mx.x) / sum.x, expf(x.y - mx.y) / sum.y, expf(x.z - mx.z) / sum.z, expf(x.w - mx.w) / sum.w);
+    }
+}
+
+// per-case part of kLogregCost for four cases per workgroup: max and its multiplicity are order-free, so the values are the
+// one-lane kernel's bit for bit
+__global__ void __launch_bounds__(WIDE_T) k_logreg_cost_wide(const float* __restrict__ labels, const float* __restrict__ probs,
+                                                             float* labelLogProbs, float* correctProbs, int numCases, int numOut) {
+    __shared__ float4 sh[WIDE_T];
+    const size_t n = (size_t)blockIdx.x * 4;
+    const float4* src = reinterpret_cast<const float4*>(probs + n);
+    const size_t rowStride = (size_t)numCases / 4;
+    float4 mx = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f);
+    for (int j = threadIdx.x; j < numOut; j += WIDE_T) {
+        const float4 x = src[j * rowStride];
+        mx = make_float4(fmaxf(mx.x, x.x), fmaxf(mx.y, x.y), fmaxf(mx.z, x.z), fmaxf(mx.w, x.w));
+    }
+    mx = wide_reduce(mx, sh, true);
+    float4 cnt = make_float4(0.f, 0.f, 0.f, 0.f);   // counts up to numOut: exact in float
+    for (int j = threadIdx.x; j < numOut; j += WIDE_T) {
+        const float4 x = src[j * rowStride];
+        cnt.x += x.x == mx.x; cnt.y += x.y == mx.y; cnt.z += x.z == mx.z; cnt.w += x.w == mx.w;
+    }
+    cnt = wide_reduce(cnt, sh, false);
+    if (threadIdx.x < 4) {
+        const int e = threadIdx.x;
+        const float maxp = e == 0 ? mx.x : e == 1 ? mx.y : e == 2 ? mx.z : mx.w;
+        const float c = e == 0 ? cnt.x : e == 1 ? cnt.y : e == 2 ? cnt.z : cnt.w;
+        const int label = (int)labels[n + e];
+        const float lp = probs[(size_t)label * numCases + n + e];
+        labelLogProbs[n + e] = logf(lp);
+        correctProbs[n + e] = lp == maxp ? 1.0f / c : 0.f;
+    }
+}
+
+// the two sums of k_logreg_cost_sums over per-case values that are already there, added in that kernel's order
+__global__ void __launch_bounds__(RED_T) k_logreg_pair_sums(const float* __restrict__ labelLogProbs, const float* __restrict__ correctProbs,
+                                                            double* sums, int numCases) {
+    __shared__ double shl[RED_T], shc[RED_T];
+    double accL = 0.0, accC = 0.0;
+    for (int n = threadIdx.x; n < numCases; n += RED_T) {
+        accL += (double)labelLogProbs[n];
+        accC += (double)correctProbs[n];
+    }
+    shl[threadIdx.x] = accL;
+    shc[threadIdx.x] = accC;
+    __syncthreads();
+    for (int s = RED_T / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            shl[threadIdx.x] += shl[threadIdx.x + s];
+            shc[threadIdx.x] += shc[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sums[0] = shl[0];
+        sums[1] = shc[0];
+    }
+}
+
 // kLogregCost (layer_kernels.cu:41-74)
 __global__ void k_logreg_cost(const float* __restrict__ labels, const float* __restrict__ probs, float* labelLogProbs,
                               float* correctProbs, int numCases, int numOut) {
@@ -572,6 +674,9 @@ __global__ void k_logreg_softmax_grad(const float* __restrict__ labels, const fl
 }  // namespace mc
 
 using namespace mc;
+
+// classifiers of MC_WIDE_CLASSES (64) classes or more take the class-parallel kernels (whole float4 groups of cases only)
+static inline bool wide_classifier(int numCases, int numOut) { return numOut >= 64 && numCases % 4 == 0; }
 
 extern "C" {
 
@@ -778,6 +883,10 @@ int mc_weights_update_spans(float* weights, float* inc, const float* grad, const
 
 int mc_softmax(const float* input, float* target, int numCases, int numOut, mcStream_t s) {
     MC_REQUIRE(input && target && numCases > 0 && numOut > 0, "mc_softmax: bad arguments");
+    if (wide_classifier(numCases, numOut) && aligned16(input) && aligned16(target)) {
+        hipLaunchKernelGGL(k_softmax_wide, dim3(numCases / 4), dim3(WIDE_T), 0, S(s), input, target, numCases, numOut);
+        return launch_status("mc_softmax");
+    }
     hipLaunchKernelGGL(k_softmax, dim3(ceil_div(numCases, 64)), dim3(64), 0, S(s), input, target, numCases, numOut);
     return launch_status("mc_softmax");
 }
@@ -793,6 +902,11 @@ int mc_compute_logreg_cost(const float* labels, const float* probs, float* label
 int mc_compute_logreg_cost_sums(const float* labels, const float* probs, float* labelLogProbs, float* correctProbs, double* sums,
                                 int numCases, int numOut, mcStream_t s) {
     MC_REQUIRE(labels && probs && labelLogProbs && correctProbs && sums && numCases > 0 && numOut > 0, "mc_compute_logreg_cost_sums: bad arguments");
+    if (wide_classifier(numCases, numOut) && aligned16(probs)) {
+        hipLaunchKernelGGL(k_logreg_cost_wide, dim3(numCases / 4), dim3(WIDE_T), 0, S(s), labels, probs, labelLogProbs, correctProbs, numCases, numOut);
+        hipLaunchKernelGGL(k_logreg_pair_sums, dim3(1), dim3(RED_T), 0, S(s), labelLogProbs, correctProbs, sums, numCases);
+        return launch_status("mc_compute_logreg_cost_sums");
+    }
     hipLaunchKernelGGL(k_logreg_cost_sums, dim3(1), dim3(RED_T), 0, S(s), labels, probs, labelLogProbs, correctProbs, sums, numCases, numOut);
     return launch_status("mc_compute_logreg_cost_sums");
 }
@@ -801,6 +915,15 @@ int mc_softmax_logreg(const float* labels, const float* input, float* probs, flo
                       float* gradTarget, int add, float coeff, int numCases, int numOut, mcStream_t s) {
     MC_REQUIRE(labels && input && probs && labelLogProbs && correctProbs && sums && numCases > 0 && numOut > 0, "mc_softmax_logreg: bad arguments");
     MC_REQUIRE(probs != input, "mc_softmax_logreg: probs must not alias the input");
+    if (wide_classifier(numCases, numOut) && aligned16(input) && aligned16(probs)) {   // the class-parallel family, launch by launch
+        hipLaunchKernelGGL(k_softmax_wide, dim3(numCases / 4), dim3(WIDE_T), 0, S(s), input, probs, numCases, numOut);
+        hipLaunchKernelGGL(k_logreg_cost_wide, dim3(numCases / 4), dim3(WIDE_T), 0, S(s), labels, probs, labelLogProbs, correctProbs, numCases, numOut);
+        hipLaunchKernelGGL(k_logreg_pair_sums, dim3(1), dim3(RED_T), 0, S(s), labelLogProbs, correctProbs, sums, numCases);
+        if (gradTarget)
+            hipLaunchKernelGGL(k_logreg_softmax_grad, dim3(ceil_div(numCases, 64), numOut), dim3(64), 0, S(s), labels, probs, gradTarget, add != 0, coeff,
+                               numCases, numOut);
+        return launch_status("mc_softmax_logreg");
+    }
     hipLaunchKernelGGL(k_softmax_logreg, dim3(1), dim3(RED_T), 0, S(s), labels, input, probs, labelLogProbs, correctProbs, sums, gradTarget,
                        add != 0, coeff, numCases, numOut);
     return launch_status("mc_softmax_logreg");

@@ -403,7 +403,11 @@ int mc_set_autotune(int enabled);
  * SoftmaxLayer::fpropActs (Kernel/src/layers/layer.cu:612-622, five NVMatrix ops there),
  * computeLogregCost / computeLogregGrad / computeSoftmaxGrad / computeLogregSoftmaxGrad
  * (Kernel/src/layers/layer_kernels.cu:198-294).  probs/acts are (numOut, numCases) row-major,
- * labels (1, numCases) float class indices. */
+ * labels (1, numCases) float class indices.
+ * Two kernel families, chosen by the shape alone: below 64 classes one lane walks the classes of a case (sums in class
+ * order); from 64 classes on (and numCases a multiple of 4) a workgroup shares four cases and adds in a fixed tree
+ * (1000 classes x 128 cases: softmax 385 -> 7.5 us, cost 100 -> 8 us).  Deterministic either way; mc_softmax_logreg
+ * takes the same family as the separate calls, so its bit-equality with them holds for every shape. */
 int mc_softmax(const float* input, float* target, int numCases, int numOut, mcStream_t stream);
 int mc_compute_logreg_cost(const float* labels, const float* probs, float* labelLogProbs,
                            float* correctProbs, int numCases, int numOut, mcStream_t stream);

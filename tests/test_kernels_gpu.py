@@ -330,8 +330,9 @@ def test_bias_and_reductions():
     assert abs(out.item() - v.astype(np.float64).sum()) < 1e-9
 
 
-@pytest.mark.parametrize("N,K", [(128, 10), (16, 10), (128, 100), (5, 7), (2500, 10)])
+@pytest.mark.parametrize("N,K", [(128, 10), (16, 10), (128, 100), (5, 7), (2500, 10), (128, 1000), (64, 64), (130, 100), (256, 1000)])
 def test_softmax_logreg(N, K):
+    # (64 classes and more, whole float4 groups of cases: the class-parallel kernels; (130, 100) stays with the one-lane family)
     m = mc()
     rng = np.random.default_rng(21)
     x = (rng.standard_normal((K, N)) * 4).astype(np.float32)
