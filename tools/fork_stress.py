@@ -15,4 +15,9 @@ for net, cases, mini in (("nin", 10 * 128, 128), ("imagenet", 6 * 128, 128), ("1
     bad = [k for k in b if (k.startswith("cost:") or k[0] in "WB") and not (np.array_equal(a[k], b[k]) and np.isfinite(b[k]).all())]
     print(net, "forked steps", int(a["forkedSteps"]), "vs", int(b["forkedSteps"]), "mismatching tensors:", bad, "%.0fs" % (time.time() - t0), flush=True)
     assert not bad
+    # the same through the one-rank RCCL path: gradient buckets are reduced behind the branch stream (or both streams)
+    c, _ = t.run_child(single_rank_comm=1, **kw)
+    bad = [k for k in b if (k.startswith("cost:") or k[0] in "WB") and not np.array_equal(c[k], b[k])]
+    print(net, "with a communicator: forked steps", int(c["forkedSteps"]), "mismatching tensors:", bad, flush=True)
+    assert not bad
 print("ok")
