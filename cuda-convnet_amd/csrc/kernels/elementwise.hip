@@ -459,6 +459,32 @@ __global__ void __launch_bounds__(WIDE_T) k_logreg_cost_wide(const float* __rest
     }
 }
 
+// kSoftmaxGrad for wide classifiers: target = y * (g - sum_j g_j y_j), the dot product added in the fixed tree
+__global__ void __launch_bounds__(WIDE_T) k_softmax_grad_wide(const float* __restrict__ y, const float* __restrict__ g, float* target, bool add,
+                                                              int numCases, int numOut) {
+    __shared__ float4 sh[WIDE_T];
+    const size_t n = (size_t)blockIdx.x * 4;
+    const float4* y4 = reinterpret_cast<const float4*>(y + n);
+    const float4* g4 = reinterpret_cast<const float4*>(g + n);
+    float4* t4 = reinterpret_cast<float4*>(target + n);
+    const size_t rowStride = (size_t)numCases / 4;
+    float4 dot = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = threadIdx.x; j < numOut; j += WIDE_T) {
+        const float4 a = g4[j * rowStride], b = y4[j * rowStride];
+        dot.x += a.x * b.x; dot.y += a.y * b.y; dot.z += a.z * b.z; dot.w += a.w * b.w;
+    }
+    dot = wide_reduce(dot, sh, false);
+    for (int j = threadIdx.x; j < numOut; j += WIDE_T) {
+        const float4 a = g4[j * rowStride], b = y4[j * rowStride];
+        float4 v = make_float4(b.x * (a.x - dot.x), b.y * (a.y - dot.y), b.z * (a.z - dot.z), b.w * (a.w - dot.w));
+        if (add) {
+            const float4 t = t4[j * rowStride];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        t4[j * rowStride] = v;
+    }
+}
+
 // the two sums of k_logreg_cost_sums over per-case values that are already there, added in that kernel's order
 __global__ void __launch_bounds__(RED_T) k_logreg_pair_sums(const float* __restrict__ labelLogProbs, const float* __restrict__ correctProbs,
                                                             double* sums, int numCases) {
@@ -940,6 +966,10 @@ int mc_compute_logreg_grad(const float* labels, const float* probs, float* targe
 int mc_compute_softmax_grad(const float* acts, const float* actsGrad, float* target, int add, int numCases, int numOut,
                             mcStream_t s) {
     MC_REQUIRE(acts && actsGrad && target && numCases > 0 && numOut > 0, "mc_compute_softmax_grad: bad arguments");
+    if (wide_classifier(numCases, numOut) && aligned16(acts) && aligned16(actsGrad) && aligned16(target) && target != actsGrad) {
+        hipLaunchKernelGGL(k_softmax_grad_wide, dim3(numCases / 4), dim3(WIDE_T), 0, S(s), acts, actsGrad, target, add != 0, numCases, numOut);
+        return launch_status("mc_compute_softmax_grad");
+    }
     hipLaunchKernelGGL(k_softmax_grad, dim3(ceil_div(numCases, 64)), dim3(64), 0, S(s), acts, actsGrad, target, add != 0,
                        numCases, numOut);
     return launch_status("mc_compute_softmax_grad");
