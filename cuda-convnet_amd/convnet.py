@@ -148,6 +148,10 @@ class ConvNet(IGPUModel):
         whole = dp.global_cases(batch_data[2][0].shape[1], self.minibatch_size, self.world) if self.world > 1 else 0
         self.libmodel.startBatch(mats, not train, whole)
 
+    def finish_batch(self):
+        # data parallel: every rank trained / tested on its shard; report (and checkpoint on) the sums over all of them
+        return dp.sum_costs(self.libmodel.finishBatch(), self.world)
+
     def aggregate_test_outputs(self, test_outputs):
         """[(costs {name: [values]}, cases)] per batch -> one (summed costs, total cases)."""
         total = dict((name, list(values)) for name, values in test_outputs[0][0].items())

@@ -543,7 +543,9 @@ int mc_describe_conv_filter_acts(char* out, int outLen, int reluBits, int numIma
                                  int numGroups) {
     MC_REQUIRE(out && outLen > 0, "mc_describe_conv_filter_acts: no output buffer");
     out[0] = 0;
-    static float dummy[4];   // never dereferenced: nothing is launched
+    // never dereferenced: nothing is launched.  16-byte aligned on purpose: the entry picks its vector / scalar instantiation (and
+    // with it the autotune cache it consults) from the operands' alignment, and the description is of the aligned case.
+    alignas(16) static float dummy[4];
     set_describe(out, outLen);
     const int rc = conv_fwd_entry(dummy, dummy, dummy, nullptr, reluBits ? MC_NEURON_RELU : MC_NEURON_NONE, numImages, numImgColors, imgSizeY, imgSizeX,
                                   numFilters, filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 0.f, 1.f,

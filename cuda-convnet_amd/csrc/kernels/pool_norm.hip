@@ -728,7 +728,10 @@ static int max_undo_entry(const char* who, bool relu, const float* images, const
     MC_REQUIRE((size_t)numFilters * imgSize * imgSize * numImages < (1ull << 31), "%s: tensor exceeds 32-bit indexing", who);
     const bool v = use_vec(numImages, {images, maxGrads, maxActs, target});
     static const bool nos2 = getenv("MC_MAXUNDO_NOS2") != nullptr;
-    if (v && numFilters <= 65535 && strideX == 2 && subsX <= 4 && !nos2) {
+    // k_max_undo_s2 holds 2 x 2 windows per 2 x 2 pixel block.  Blocks start on even pixels, windows on startX + 2 o: a size-4
+    // window with an odd start overlaps a block three ways per axis (starts x0 - 3, x0 - 1, x0 + 1) and takes the general kernel.
+    const bool s2fits = subsX <= 3 || (subsX == 4 && (startX & 1) == 0);
+    if (v && numFilters <= 65535 && strideX == 2 && s2fits && !nos2) {
         dim3 g2;
         const Map2D mp = make_map2d(numImages, (imgSize + 1) / 2, (imgSize + 1) / 2, numFilters, g2);
         if (relu) hipLaunchKernelGGL(k_max_undo_s2<true>, g2, dim3(256), 0, S(s), images, maxGrads, maxActs, target, numImages, imgSize, subsX, startX, outputsX, scaleTargets, scaleOutput, mp);

@@ -466,6 +466,7 @@ float* ConvNet::workspace(size_t bytes) {
             }
             _branchWorkspaceBytes = (bytes + (4u << 20)) / (4u << 20) * (4u << 20);
             RT_HIP(hipMalloc(reinterpret_cast<void**>(&_branchWorkspace), _branchWorkspaceBytes));
+            DeviceAllocator::get().noteForeignAllocation();   // a graph captured with MC_STEP_FORK=graph holds the old address
         }
         return _branchWorkspace;
     }
@@ -673,6 +674,7 @@ bool ConvNet::captureStep(StepGraph& g, DevMatV& mb) {
         if (_branchWorkspace) RT_HIP(hipFree(_branchWorkspace));
         _branchWorkspaceBytes = _workspaceBytes;
         RT_HIP(hipMalloc(reinterpret_cast<void**>(&_branchWorkspace), _branchWorkspaceBytes));
+        DeviceAllocator::get().noteForeignAllocation();
     }
     _forkThisStep = _forkGraph;
     bool ok = hipStreamBeginCapture(_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
@@ -686,6 +688,7 @@ bool ConvNet::captureStep(StepGraph& g, DevMatV& mb) {
                     RT_MC(mc_accumulate_f64(c->deviceSlots() + (size_t)CostLayer::GRAPH_TOTAL * c->numCostValues(),
                                             c->deviceSlots() + (size_t)CostLayer::GRAPH_SLOT * c->numCostValues(), c->numCostValues(), ST()));
             bprop(PASS_TRAIN);
+            if (getenv("MC_TEST_FAIL_CAPTURE")) throw std::runtime_error("MC_TEST_FAIL_CAPTURE");   // test hook: fail after bprop, before the update
             updateWeights();
         } catch (std::exception& e) {
             ok = false;
@@ -707,6 +710,11 @@ bool ConvNet::captureStep(StepGraph& g, DevMatV& mb) {
     if (!ok) {
         (void)hipGetLastError();   // the failed capture's sticky error is not the next launch's
         g.bad = true;
+        // Nothing ran, but the host side walked part of a step: put back what an eager step relies on.  Without this a weight
+        // tensor whose gradient product was "queued" keeps _numUpdates > 0 and the eager step that follows ADDS onto the stale
+        // gradient of the step before; arrival counters left half way skip or repeat layers.
+        for (Layer* l : _layers) l->abortPass();
+        for (Weights* w : _allWeights) w->markUpdated();
         if (getenv("MC_STEP_GRAPH_VERBOSE")) fprintf(stderr, "[libkernel] step graph not captured (%s): steps of this shape stay eager\n", g.why.c_str());
     }
     return ok;
@@ -755,7 +763,9 @@ void ConvNet::runEagerStep(StepGraph& g, DevMatV& mb, int cases, unsigned long l
     }
     _forkedSteps += _forkThisStep;
     _forkThisStep = false;
-    g.allocStamp = DeviceAllocator::get().allocations();
+    // With a captured graph alive the stamp must stay the capture's: re-stamping after an eager step that (re)allocated would make
+    // the graph's stale addresses look current to the next trainStep, which compares the two and drops the graph on a mismatch.
+    if (!g.exec) g.allocStamp = DeviceAllocator::get().allocations();
     if (randDraws() != draws) _stochastic = true;   // dropout & co. take new random numbers every step
     g.eagerRuns++;
 }

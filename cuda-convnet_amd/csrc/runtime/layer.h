@@ -133,6 +133,8 @@ public:
     virtual void bprop(PASS_TYPE passType);                 // layer.cu:117-123
     void bprop(DevMat& v, PASS_TYPE passType);              // layer.cu:125-167
     virtual void reset();
+    // a pass was abandoned half way (an exception during a step capture): forget everything that only holds within one pass
+    virtual void abortPass() { reset(); }
     int getRcvdFInputs() const { return _rcvdFInputs; }
     int getRcvdBInputs() const { return _rcvdBInputs; }
     int incRcvdBInputs() { return ++_rcvdBInputs; }
@@ -213,6 +215,7 @@ public:
     unsigned* bitsBuffer(int rows, int ld);
     void setBitsValid(bool v) { _bitsValid = v; }
     const unsigned* validBits() const { return _bitsValid ? reinterpret_cast<const unsigned*>(_bits.data()) : nullptr; }
+    void abortPass() override { Layer::abortPass(); _gradMasked = false; _bitsValid = false; }
 
 protected:
     void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
@@ -322,6 +325,7 @@ protected:
 class SoftmaxLayer : public Layer {
 public:
     SoftmaxLayer(ConvNet* convNet, PyObject* paramsDict) : Layer(convNet, paramsDict) {}
+    void abortPass() override { Layer::abortPass(); _gradDone = false; }
 
 protected:
     void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
@@ -518,6 +522,7 @@ public:
     // The softmax layer below runs softmax + this cost (+ the gradient into `grad`, nullable) as one launch and tells the
     // cost so: its own fpropActs then has nothing left to do this pass.
     void fusedTail(const float* labels, const float* in, float* probs, float* grad, int numCases, int numOut);
+    void abortPass() override { CostLayer::abortPass(); _fusedThisPass = false; }
 
 protected:
     void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;

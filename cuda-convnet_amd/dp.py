@@ -62,3 +62,25 @@ def global_cases(cases, minibatch, world):
     the world size): the third argument of libkernel.startBatch, from which it takes each minibatch's true global size."""
     t = cases % (minibatch * world)
     return cases - t if 0 < t < world else cases
+
+
+def sum_costs(result, world):
+    """finishBatch's (costs {name: [values]}, cases) of THIS rank's shard -> the same pair for the whole batch, on every rank:
+    cost values and case counts are summed over the ranks through the CPU control group (float64, one small all-reduce per
+    batch -- the reference has one device and simply reads the sums, Python/convnet.py:120-134).  What rank 0 prints, what a
+    test pass reports and what conditional_save compares are then about the global batch, not about 1 / world of it."""
+    if world <= 1:
+        return result
+    import torch
+    costs, cases = result
+    names = sorted(costs)                      # every rank holds the same model: same names, same value counts
+    flat = [float(cases)] + [float(v) for name in names for v in costs[name]]
+    t = torch.tensor(flat, dtype=torch.float64)
+    init_control_group().all_reduce(t)         # sum
+    flat = t.tolist()
+    out, at = {}, 1
+    for name in names:
+        k = len(costs[name])
+        out[name] = flat[at:at + k]
+        at += k
+    return dict((name, out[name]) for name in costs), int(round(flat[0]))

@@ -28,6 +28,10 @@ def main():
     prof = libkernel.getProfile()
     libkernel.syncWithHost()
     res = {"cases": np.array([cost[1]]), "allreduce": np.array(prof.get("dp/allreduce:bytes", (0, 0.0)))}
+    whole, seen = dp.sum_costs(cost, world)          # what convnet.ConvNet.finish_batch hands the driver on every rank
+    res["globalCases"] = np.array([seen])
+    for name, vals in whole.items():
+        res["cost:" + name] = np.array(vals, dtype=np.float64)
     for l in layers:
         if "weights" in l:
             for i, w in enumerate(l["weights"]):

@@ -39,16 +39,22 @@ def main():
     mine = [d[:, cols] for d in data]
     net = GoldenNet(layers, world=world)
     total = dp.global_cases(cases, mini, world)
+    shard_costs = {}
     for i, s in enumerate(range(0, mine[0].shape[1], mini)):
         net.global_cases = min(mini * world, total - i * mini * world)     # what libkernel derives from startBatch's third argument
-        net.fprop([d[:, s:s + mini] for d in mine])
+        for name, vals in net.fprop([d[:, s:s + mini] for d in mine]).items():
+            shard_costs[name] = [a + float(b) for a, b in zip(shard_costs.get(name, [0.0] * len(vals)), vals)]
         net.bprop()
         for store in (net.wgrads, net.bgrads):
             for k in sorted(store, key=str):
                 t = torch.from_numpy(store[k])
                 dist.all_reduce(t)           # sum, in place (what ncclAllReduce does on the GPU path)
         net.update()
-    res = {}
+    # what convnet.ConvNet.finish_batch reports: this rank's (costs, cases) summed over the ranks
+    costs, seen = dp.sum_costs((shard_costs, mine[0].shape[1]), world)
+    res = {"cases": np.array(seen)}
+    for name, vals in costs.items():
+        res["cost:" + name] = np.array(vals, dtype=np.float64)
     for l in layers:
         if "weights" in l:
             res["W:" + l["name"]] = net.weight(l["name"], 0)

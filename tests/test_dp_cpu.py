@@ -55,8 +55,15 @@ def test_two_rank_gloo_equals_single_process(tmp_path):
     layers, dims, classes = modelutil.load_net("gc-small", seed=11)
     data = modelutil.synthetic_batch(dims, classes, 43)
     net = GoldenNet(layers)
+    want = {}
     for s in range(0, 43, 16):
-        net.train_step([d[:, s:s + 16] for d in data])
+        for name, vals in net.train_step([d[:, s:s + 16] for d in data]).items():
+            want[name] = [a + float(b) for a, b in zip(want.get(name, [0.0] * len(vals)), vals)]
+    # what rank 0 prints and checkpoints on is the GLOBAL batch: costs and case counts summed over the ranks (dp.sum_costs)
+    assert int(r0["cases"]) == int(r1["cases"]) == 43
+    for name, vals in want.items():
+        np.testing.assert_allclose(r0["cost:" + name], vals, rtol=1e-5)
+        np.testing.assert_array_equal(r0["cost:" + name], r1["cost:" + name])
     for l in layers:
         if "weights" in l:
             np.testing.assert_allclose(r0["W:" + l["name"]], net.weight(l["name"], 0), rtol=1e-4, atol=1e-6)

@@ -52,8 +52,14 @@ def test_two_gpus_equal_the_oracle_on_global_minibatches(tmp_path):
     layers, dims, classes = modelutil.load_net(net_name, seed=11)
     data = modelutil.synthetic_batch(dims, classes, cases)
     gold = GoldenNet(layers)
+    want = {}
     for s in range(0, cases, 2 * mini):
-        gold.train_step([d[:, s:s + 2 * mini] for d in data])
+        for name, vals in gold.train_step([d[:, s:s + 2 * mini] for d in data]).items():
+            want[name] = [a + float(b) for a, b in zip(want.get(name, [0.0] * len(vals)), vals)]
+    # rank 0 reports the global batch: costs and cases summed over the ranks (dp.sum_costs; SURVEY 8e "cost scalars: sum on host")
+    assert int(r0["globalCases"][0]) == int(r1["globalCases"][0]) == dp.global_cases(cases, mini, 2)
+    for name, vals in want.items():
+        np.testing.assert_allclose(r0["cost:" + name], vals, rtol=2e-4, atol=1e-3)
     for l in layers:
         if "weights" in l:
             for k, want in (("W0:" + l["name"], gold.weight(l["name"], 0)), ("B:" + l["name"], gold.B[l["name"]])):

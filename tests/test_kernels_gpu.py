@@ -151,6 +151,9 @@ POOL_CASES = [  # N, C, S, size, start, stride
     (128, 96, 32, 3, 0, 2), (128, 10, 8, 8, 0, 1), (16, 32, 16, 3, 0, 2), (128, 16, 8, 2, 1, 2),
     (6, 16, 6, 4, -2, 4), (5, 3, 7, 3, 0, 2),
     (128, 96, 55, 2, 1, 2), (128, 256, 27, 2, 1, 2),   # the imagenet net's pools (2x2, stride 2, start 1) at full size
+    # size 4 / stride 2: an odd start puts three windows over a 2-pixel block per axis (the stride-2 undo kernel holds two:
+    # such shapes must take the general kernel), an even start two
+    (16, 8, 9, 4, -1, 2), (16, 8, 9, 4, 1, 2), (16, 8, 10, 4, 0, 2), (16, 8, 9, 4, -2, 2),
 ]
 
 

@@ -155,6 +155,22 @@ def test_captured_steps_equal_eager_steps(net_name, cases, mini):
         np.testing.assert_allclose(got["cost:" + k][0], v[0], rtol=2e-4, atol=1e-3)
 
 
+def test_failed_capture_falls_back_to_a_clean_eager_step():
+    """A step capture that fails half way (here: a test hook throws after the captured bprop, before the update) has walked the
+    host side of part of a step without running anything: weight tensors count a queued gradient, layers hold arrival counters
+    and per-pass flags.  ConvNet::captureStep puts all of that back, so the eager step that follows -- and the rest of the batch
+    -- is bit-identical to a run that never tried to capture."""
+    cases, mini = 5 * 32 + 7, 32
+    got, _ = run_child(net="80sec", cases=cases, mini=mini, init_w=0.05, _env={"MC_STEP_GRAPH": "1", "MC_TEST_FAIL_CAPTURE": "1"})
+    ref, _ = run_child(net="80sec", cases=cases, mini=mini, init_w=0.05, _env={"MC_NO_STEP_GRAPH": "1"})
+    assert int(got["graphReplays"]) == 0 and int(got["numCases"]) == int(ref["numCases"]) == cases
+    for k in ref:
+        if k.startswith("cost:"):
+            np.testing.assert_allclose(got[k], ref[k], rtol=1e-12, atol=1e-9)
+        elif k[0] in "WB":
+            assert np.array_equal(got[k], ref[k]), k
+
+
 @pytest.mark.parametrize("net_name,cases,mini", [("nin-tiny", 3 * 32 + 7, 32), ("example-small", 2 * 16 + 3, 16)])
 def test_warm_up_leaves_no_trace(net_name, cases, mini):
     """Before the first training step of a batch the runtime dry-runs one forward + backward pass per minibatch shape (full and

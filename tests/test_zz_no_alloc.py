@@ -54,6 +54,51 @@ def test_noalloc_weight_grad_equals_workspace_form_twice_second_smaller():
     assert relerr(got, exp) < TOL
 
 
+def test_noalloc_entry_first_on_a_fresh_shape_under_stream_capture():
+    """The headline contract, not only the bits: on a shape the library has never seen (no cached tile: the static rule's tile
+    runs) the entry point is called FIRST, inside a stream capture -- where hipMalloc, hipFree, event queries and blocking calls
+    are illegal and would invalidate the capture -- and the device's free memory is the same before and after.  The captured
+    graph is launched twice; the result equals the workspace form (called afterwards, which also tunes the shape) bit for bit."""
+    import ctypes
+    import torch
+    import mckernels as m
+    hip = ctypes.CDLL("libamdhip64.so")   # the runtime torch already loaded
+    rng = np.random.default_rng(78)
+    N, C, H, fs, F, pad, stride, groups = 48, 24, 11, 3, 40, 1, 1, 1          # used by no other test: untuned
+    M = _modules(H, fs, pad, stride)
+    img = rng.standard_normal((C * H * H, N)).astype(np.float32)
+    hid = rng.standard_normal((F * M * M, N)).astype(np.float32)
+    geo = (N, C, H, H, F, fs, -pad, stride, M, M, groups)
+    wshape = ((C // groups) * fs * fs, F)
+    wsb = m.lib().mc_conv_weight_grad_workspace_bytes(N, C, F, fs, M * M, groups)
+    dimg, dhid, got, ref, ws = dev(img), dev(hid), nans(*wshape), nans(*wshape), nans(max(1, wsb // 4))
+    # the library's once-per-device set-up (hipGetSymbolAddress of the array, kernel attributes) happens on the first call on a
+    # device: make that call here, on another shape, so that the captured call below is an ordinary one when this test runs alone
+    _both(m, rng, 8, 4, 6, 3, 8, 1, 1, 1, 0.0, 1.0)
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    free0, tot = ctypes.c_size_t(), ctypes.c_size_t()
+    assert hip.hipMemGetInfo(ctypes.byref(free0), ctypes.byref(tot)) == 0
+    handle = ctypes.c_void_p(st.cuda_stream)
+    graph, gexec = ctypes.c_void_p(), ctypes.c_void_p()
+    assert hip.hipStreamBeginCapture(handle, 2) == 0                          # hipStreamCaptureModeRelaxed
+    rc = m.lib().mc_conv_weight_grad_noalloc(ptr(dimg), ptr(dhid), ptr(got), *geo, 0.0, 1.0, handle)
+    assert hip.hipStreamEndCapture(handle, ctypes.byref(graph)) == 0 and graph.value, "the capture was invalidated"
+    assert rc == 0, m.lib().mc_last_error().decode()
+    free1 = ctypes.c_size_t()
+    assert hip.hipMemGetInfo(ctypes.byref(free1), ctypes.byref(tot)) == 0
+    assert free1.value == free0.value, "the entry point changed the device's free memory"
+    assert hip.hipGraphInstantiate(ctypes.byref(gexec), graph, None, None, 0) == 0
+    for _ in range(2):
+        assert hip.hipGraphLaunch(gexec, handle) == 0
+    assert hip.hipStreamSynchronize(handle) == 0
+    hip.hipGraphExecDestroy(gexec)
+    hip.hipGraphDestroy(graph)
+    m.call("mc_conv_weight_grad", ptr(dimg), ptr(dhid), ptr(ref), *geo, 0.0, 1.0, ptr(ws), wsb, None)
+    assert np.array_equal(host(got), host(ref))
+    assert relerr(host(got), G.weight_acts(img, hid, *geo, partial_sum=0)) < TOL
+
+
 def test_noalloc_array_covers_the_baseline_layers():
     """The slabs of one launch are (workgroups in one round) x (tile): at most 256 x 192 x 128 floats = 25.2 MB on this
     device, so the 32 MiB array serves every shape the chunk plan produces here; the size check in the entry point guards
