@@ -25,6 +25,12 @@ NETS = {   # name -> (layer-def, layer-params, data dims, classes)
     "image-layers": ("image-layers.def", "image-layers.params", 768, 10),
     "gc-sparse": ("gc-sparse.def", "gc-sparse.params", 432, 10),
     "example-small": ("example-small.def", "example-small.params", 768, 10),
+    # the reference's own --check-grads fixture, a verbatim copy of example-layers/layers.gc.cfg + layer-params.gc.cfg (run there
+    # on `--data-provider dummy-cn-<dims>`; any 3 * S * S works, 432 = 12 x 12 images).  The other fixture it ships there,
+    # layers-example.cfg + layer-params-example.cfg, is rejected by the fork's own parser (and by ours, the same way: see
+    # tests/test_layer_parser.py::test_reference_example_config_is_rejected_as_the_reference_rejects_it); "example-small" above
+    # is its runnable analogue.
+    "gc": ("layers.gc.cfg", "layer-params.gc.cfg", 432, 10),
 }
 
 

@@ -68,6 +68,38 @@ def datagen():
          geom=np.array([N, C, H, H, F, fs, 0, 1, M, M, 1]))
 
 
+def datagen_group_sparsity():
+    """Kernel/unittest/groupSparsity/DataGen.m:1-46, statement by statement in NumPy float64 (16 x 16 x 3 inputs, 12 cases,
+    labels 1..10; MATLAB's rand -> a seeded generator): per case and channel the sum of squares, summed per distinct label,
+    times that label's case count, square root; cost = the sum of those roots; gradient = count * data / root.  INDEPENDENT of
+    oracle/ (no import from it is used here).  test.cu:74-80 compares CalculateSqrtSumSquareMatrix / CalculateGradient to it."""
+    channels, cases, imgSize, labelnum = 3, 12, 16, 10
+    rng = np.random.default_rng(20113)
+    pix = imgSize * imgSize
+    data = rng.random((pix * channels, cases)).astype(np.float32).astype(np.float64)   # the values the fp32 kernels see
+    labels = rng.integers(1, labelnum + 1, size=cases)
+    sq = data ** 2
+    compact = np.zeros((channels, cases))
+    for i in range(cases):
+        for j in range(channels):
+            compact[j, i] += sq[j * pix:(j + 1) * pix, i].sum()
+    a, c = np.unique(labels, return_inverse=True)
+    comcompact = np.zeros((channels, len(a)))
+    for i in range(cases):
+        comcompact[:, c[i]] += compact[:, i]
+    for i in range(len(a)):
+        comcompact[:, i] *= (labels == a[i]).sum()
+    comcompact = np.sqrt(comcompact)
+    cost = comcompact.sum()
+    gradient = np.zeros_like(data)
+    for i in range(cases):
+        for j in range(channels):
+            index = int(np.where(a == labels[i])[0][0])
+            gradient[j * pix:(j + 1) * pix, i] = (labels == labels[i]).sum() * data[j * pix:(j + 1) * pix, i] / comcompact[j, index]
+    save("datagen_group_sparsity.npz", acts=data.astype(np.float32), labels=labels.astype(np.float32).reshape(1, cases),
+         expected_grad=gradient, expected_cost=np.array(cost), geom=np.array([cases, channels, pix]))
+
+
 def ops():
     rng = np.random.default_rng(20112)
     N = 12
@@ -126,4 +158,5 @@ def ops():
 
 if __name__ == "__main__":
     datagen()
+    datagen_group_sparsity()
     ops()

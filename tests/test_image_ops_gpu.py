@@ -162,6 +162,23 @@ def test_group_sparsity_in_label_cost_and_grad(N, ch, P, classes):
         close(host(t), G.group_sparsity_in_label_grad(labels, acts, ch, 0.5, target=prev, scale_targets=sT), 1e-5)
 
 
+def test_group_sparsity_datagen_vector():
+    """The HIP kernels on the re-created vector of Kernel/unittest/groupSparsity/DataGen.m (tests/golden/datagen_group_sparsity.npz,
+    expected cost and gradient computed in NumPy float64 independently of the oracle): what the reference's test.cu:74-80 prints."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "datagen_group_sparsity.npz"))
+    N, ch, P = (int(v) for v in z["geom"])
+    m = mc()
+    dl, da = dev(z["labels"]), dev(z["acts"])
+    q, sq, terms, cnt = nans(ch, N), nans(ch, N), nans(ch, N), nans(1, N)
+    m.call("mc_group_sparsity_in_label_cost", ptr(dl), ptr(da), ptr(q), ptr(sq), ptr(cnt), ptr(terms), N, ch, P, None)
+    cost = float(host(terms).astype(np.float64).sum())
+    assert abs(cost - float(z["expected_cost"])) < 1e-5 * cost
+    t = nans(ch * P, N)
+    m.call("mc_group_sparsity_in_label_grad", ptr(da), ptr(sq), ptr(cnt), ptr(t), N, ch, P, 0.0, 1.0, None)
+    np.testing.assert_allclose(host(t), z["expected_grad"], rtol=1e-5, atol=1e-7)
+
+
 @pytest.mark.parametrize("N,C,P,groups,fc", [(128, 8, 64, 4, 4), (16, 6, 49, 3, 4), (5, 16, 9, 2, 8), (6, 3, 4, 1, 3)])
 def test_channel_gather_and_scatter(N, C, P, groups, fc):
     """randSparse plumbing: gather of the connected channels and the per-channel sum of their gradients, bit for bit."""

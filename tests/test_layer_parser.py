@@ -110,6 +110,40 @@ def test_reference_gc_config_parses():
     assert by["avgpool"]["start"] == -2 and by["fc10"]["inputs"] == [6, 3] or by["fc10"]["numInputs"] == [by["local32"]["outputs"], by["conv32"]["outputs"]]
 
 
+def test_reference_example_config_is_rejected_as_the_reference_rejects_it(tmp_path, capsys):
+    """example-layers/layers-example.cfg + layer-params-example.cfg (verbatim copies under configs/) are stale in the fork: the
+    norm sections say `sizeX` where NormLayerParser reads `size` (Python/layer.py:1089), and with that renamed the params file
+    has no [rnorm1] / [cnorm1] section although norm layers take scale / pow from it (layer.py:276-284, 1078-1083).  Both are
+    LayerParsingErrors in the reference (print + exit(1), layer.py:285-287); same messages, same order here."""
+    d, p = os.path.join(modelutil.CONFIGS, "layers-example.cfg"), os.path.join(modelutil.CONFIGS, "layer-params-example.cfg")
+    with pytest.raises(SystemExit):
+        modelutil.parse_net(d, p, 3072, 10, quiet=False)
+    assert "Layer 'rnorm1': required parameter 'size' missing" in capsys.readouterr().out
+    fixed, section = [], ""
+    for line in open(d).read().splitlines():
+        section = line.strip() if line.startswith("[") else section
+        fixed.append("size=" + line[6:] if section in ("[rnorm1]", "[cnorm1]") and line.startswith("sizeX=") else line)
+    d2 = tmp_path / "layers-example-size.cfg"
+    d2.write_text("\n".join(fixed) + "\n")
+    with pytest.raises(SystemExit):
+        modelutil.parse_net(str(d2), p, 3072, 10, quiet=False)
+    assert "Layer 'rnorm1' of type 'rnorm' requires extra parameters, but none given in file" in capsys.readouterr().out
+
+
+def test_shipped_gc_fixture_is_the_reference_file():
+    """configs/layers.gc.cfg and layer-params.gc.cfg are byte copies of the reference's fixture (checked where the reference
+    tree is present); the net they describe runs through --check-grads and as a whole-step case on the GPU."""
+    layers, dims, classes = modelutil.load_net("gc")
+    by = dict((l["name"], l) for l in layers)
+    assert by["local32"]["randSparse"] == [True] and by["local32"]["groups"] == [2] and by["avgpool"]["start"] == -2
+    assert by["conv32_neuron"]["neuron"]["params"] == {"a": 3.0, "b": 2.2} and by["local32_neuron"]["neuron"]["type"] == "tanh"
+    assert len(by["fc10"]["weights"]) == 2
+    if os.path.isdir(REF):
+        for ours, theirs in (("layers.gc.cfg", "example-layers/layers.gc.cfg"), ("layer-params.gc.cfg", "example-layers/layer-params.gc.cfg"),
+                             ("layers-example.cfg", "example-layers/layers-example.cfg"), ("layer-params-example.cfg", "example-layers/layer-params-example.cfg")):
+            assert open(os.path.join(modelutil.CONFIGS, ours), "rb").read() == open(os.path.join(REF, theirs), "rb").read()
+
+
 def test_conv_to_local_is_the_same_function():
     """--conv-to-local (layer.py:816-844): the filter bank tiled once per module.  The converted net computes the
     same forward pass, and after one training step the per-module weight increments of the local layer add up

@@ -175,3 +175,18 @@ def test_norm_fwd_formulas():
     s = sum(p[i:i + C] for i in range(5))
     np.testing.assert_allclose(d.reshape(x.shape), 2.0 + scale * s, rtol=1e-6)
     np.testing.assert_allclose(y.reshape(x.shape), x * (2.0 + scale * s) ** -pw, rtol=1e-5)
+
+
+# -- Kernel/unittest/groupSparsity/DataGen.m:1-46 + test.cu:74-80 : 16x16x3, 12 cases, labels 1..10; cost and gradient in closed form
+def test_datagen_group_sparsity():
+    """The fourth (and last) generator the reference ships, re-created in NumPy (tests/golden/make_golden.py, independent of
+    oracle/): the plugin's cost.gsinlabel arithmetic (PluginsSrc/src/extrautils.cu).  The reference's kernel adds 2.5e-7 to the
+    root before dividing (extrautils.cu:190), the generator does not: with roots of ~10 that is 3e-8 relative."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "datagen_group_sparsity.npz"))
+    N, ch, P = (int(v) for v in z["geom"])
+    assert z["acts"].shape == (ch * P, N)
+    cost, S, counts = G.group_sparsity_in_label_cost(z["labels"], z["acts"], ch)
+    assert abs(cost - float(z["expected_cost"])) < 1e-6 * cost
+    grad = G.group_sparsity_in_label_grad(z["labels"], z["acts"], ch, coeff=-1.0)     # the layer's bprop is -coeff * this
+    np.testing.assert_allclose(grad, z["expected_grad"], rtol=1e-5, atol=1e-7)

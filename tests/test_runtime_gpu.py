@@ -3,6 +3,7 @@ kernels through the C-ABI) against the CPU oracle net, on identical synthetic in
 dropout masks.  Tolerance: fp32 contraction tolerance rel 1e-4 (of the tensor's RMS) after a few
 SGD steps, as BASELINE.json's north_star states; costs to 1e-4 relative."""
 import os
+import re
 import subprocess
 import sys
 import tempfile
@@ -92,7 +93,13 @@ CASES = [("gc-small", 128 + 70, 128, "max"), ("nin-tiny", 128 + 70, 128, "max"),
          ("imagenet", 8 + 3, 8, "max", 0.02, 43),
          # cnorm, eltsum, cost.sum2, a grouped conv, a two-input fc and an fc straight from the data (shape of the reference's
          # example-layers/layers-example.cfg)
-         ("example-small", 64 + 22, 64, "max")]
+         ("example-small", 64 + 22, 64, "max"),
+         # the reference's own gradient-check fixture (verbatim layers.gc.cfg / layer-params.gc.cfg) as a training step; weight seed 7:
+         # with seed 42 one case's p[label] underflows to 0 and the cost is inf on both sides
+         ("gc", 64 + 22, 64, "max", 0.0, 7),
+         # THE net the headline number is quoted on, with its shipped parameters (NIN/cifar-10_def + cifar-10_params: epsW = 1,
+         # wc = 1e-5, coeff = 0.1), full size, a 16-case minibatch and a 6-case tail (the oracle needs ~20 s for these 22 cases)
+         ("nin", 16 + 6, 16, "max")]
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(str(x) for x in c))
@@ -235,6 +242,26 @@ def test_gradient_check_passes(net_name):
     got, out = run_child(net=net_name, cases=32, mini=32, check_grads=1)
     assert int(got["failures"]) == 0, out[-2000:]
     assert "TESTS PASSED" in out
+
+
+def test_reference_gc_fixture_through_check_grads():
+    """The reference's OWN integration fixture, verbatim (configs/layers.gc.cfg + layer-params.gc.cfg = example-layers/ of the
+    reference: conv with linear[3,2.2], avg-pool with start=-2, local layer with groups=2 / randSparse / stride 3 / tanh, two-input
+    fc), through --check-grads as Kernel/src/convnet/convnet.cu:262-335 runs it: every element of every tensor perturbed, forward
+    differences, relative L2 error against 0.02.  On the fork's dummy data (U[0,1), Python/data.py:236 "changed to rand") the
+    fixture is numerically marginal by construction, which the CPU oracle shows with the same rule (tests/test_golden_net.py's
+    helper on this net): initW = 0.8 saturates the softmax (weight seed 42 has a case with p[label] == 0 in fp32: cost inf), and
+    fc10's second weight matrix (initW 0.008, finite-difference step 0.1 >> the weights) sits at 0.03-0.036 relative error in
+    float64 arithmetic -- a property of the fixture, not of an implementation.  So: weight seed 7 (finite cost), every tensor
+    must pass except that one, which may land on either side of 0.02."""
+    got, out = run_child(net="gc", cases=32, mini=32, check_grads=1, seed=7)
+    verdicts = dict((m.group(2), m.group(1)) for m in re.finditer(r"\((PASS|\*\*\*\*FAIL\*\*\*\*)\) (.+) GRADIENT CHECK", out))
+    assert len(verdicts) == 7, out[-3000:]        # conv32 / local32 weights + biases, fc10 weights[0], weights[1], biases
+    failed = sorted(k for k, v in verdicts.items() if v != "PASS")
+    marginal = [k for k in verdicts if "fc10" in k and "[1]" in k]
+    assert len(marginal) == 1, verdicts
+    assert set(failed) <= set(marginal), out[-3000:]
+    assert int(got["failures"]) == len(failed)
 
 
 def test_image_layers_forward_matches_oracle():
