@@ -23,3 +23,6 @@ rows = sorted(((k, c / 5.0, ms / c) for k, (c, ms) in tab.items() if c and ms), 
 print("%s mb=%d: %.0f images/s, %.3f ms/step, cost/case %.4f; kernel time/step %.3f ms" % (net, mb, mb * steps / dt, dt / steps * 1e3, list(costs.values())[0][0] / n, sum(r[1] * r[2] for r in rows)))
 print("   steps replayed as graphs %d, eager steps with the weight-gradient branch %d" % (counters.get("net/step_graph:replays", 0), counters.get("net/step_fork:steps", 0)))
 for k, c, ms in rows[:int(sys.argv[4]) if len(sys.argv) > 4 else 10]: print("   %-52s x%.0f %8.4f ms" % (k, c, ms))
+if len(sys.argv) > 5:   # the whole event table (every launch timed, one stream: the kernels' own times) as JSON
+    json.dump({"net": net, "minibatch": mb, "images_per_s": mb * steps / dt, "ms_per_step": dt / steps * 1e3,
+               "launches": [{"name": k, "per_step": c, "avg_ms": ms} for k, c, ms in rows]}, open(sys.argv[5], "w"), indent=1)
