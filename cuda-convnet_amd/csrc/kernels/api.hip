@@ -85,11 +85,20 @@ __global__ void __launch_bounds__(256) k_splitk_reduce_tall(const float4* __rest
     const size_t total4 = (size_t)m * n4;
     const size_t e = (size_t)blockIdx.x * 16 + cg;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e < total4)
-        for (int q = qg; q < chunks; q += 16) {
+    if (e < total4) {
+        int q = qg;   // eight slabs' loads in flight, added in slab order (same bits as one at a time)
+        for (; q + 7 * 16 < chunks; q += 8 * 16) {
+            float4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = slabs[(size_t)(q + 16 * u) * total4 + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+        }
+        for (; q < chunks; q += 16) {
             const float4 x = slabs[(size_t)q * total4 + e];
             acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
         }
+    }
     sh[qg][cg] = acc;
     __syncthreads();
     for (int half = 8; half > 0; half >>= 1) {
@@ -269,9 +278,22 @@ int reduce_slabs(const float* slabs, float* C, int m, long n, int chunks, float 
     return launch_status("conv split-K reduce");
 }
 
-int pick_gemm_chunks(int m, int n, int k) {
+// kc: the weight-gradient orientation (transA = 0, transB = 1: both operands k-contiguous), the one with 16x16x4 tiles
+int pick_gemm_chunks(int m, int n, int k, bool kc) {
     static const char* forced = getenv("MC_GEMM_CHUNKS");   // tuning knob (benchmarks only)
     if (forced && forced[0]) return atoi(forced) < 1 ? 1 : atoi(forced);
+    static const bool nomf = getenv("MC_IGEMM_NOMF") != nullptr;
+    if (kc && !nomf && k >= 2048) {
+        // A weight gradient whose whole output is one 16x16x4 tile (NIN's cccp layers): one workgroup per K chunk owns all of C,
+        // so each operand element is fetched once device-wide and no matrix work is padding.  One round of workgroups: a chunk
+        // per CU when k allows 256 per chunk; with fewer chunks than that the tile is halved along its rows (the launch picks).
+        if (mf_whole_output(m, n)) {
+            long want = num_cus();
+            const long maxc = k / 256;
+            if (want > maxc) want = maxc;
+            return want < 1 ? 1 : (int)want;
+        }
+    }
     // tiles of the shape launch_rows_cols will pick for a long-k product: 128 x 192 when that pads the
     // column extent less, else 96 x 128
     const bool wide = (long)ceil_div(n, 192) * 192 < (long)ceil_div(n, 128) * 128 && m > 96;
@@ -458,8 +480,9 @@ int mc_local_img_acts(const float* hidActs, const float* filters, float* targets
 
 size_t mc_gemm_workspace_bytes(int m, int n, int k) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
-    const int chunks = pick_gemm_chunks(m, n, k);
-    return chunks > 1 ? (size_t)chunks * m * n * sizeof(float) : 0;
+    const int c0 = pick_gemm_chunks(m, n, k, false), c1 = pick_gemm_chunks(m, n, k, true);   // the caller does not say which orientation
+    const int chunks = c0 > c1 ? c0 : c1;
+    return chunks > 1 ? (size_t)chunks * ((size_t)m * n + m) * sizeof(float) : 0;
 }
 // (Measured and dropped: cutting the 160 / 192 columns of the dense weight gradients into 128 + remainder, two products on
 // exact tiles instead of one padded to 256 columns -- cccp1 121 -> 115 us, but cccp2 67 -> 75 and cccp3 42 -> 48: the second
@@ -477,7 +500,7 @@ static int gemm_entry(const char* who, const float* A, const float* B, float* C,
     MC_REQUIRE((size_t)(transA ? k : m) * lda < (1ull << 30) && (size_t)(transB ? n : k) * ldb < (1ull << 30) &&
                    (size_t)m * ldc < (1ull << 30) && (!mask || (size_t)m * ldmask < (1ull << 30)),
                "%s: operand exceeds the 4 GiB buffer-descriptor range", who);
-    int chunks = (bitsOut || bitsIn) ? 1 : pick_gemm_chunks(m, n, k);   // the bit-mask epilogues live in the unsplit product
+    int chunks = (bitsOut || bitsIn) ? 1 : pick_gemm_chunks(m, n, k, !transA && transB);   // the bit-mask epilogues live in the unsplit product
     // with row sums the chunks' m partial sums each follow the slabs
     const size_t slabBytes = (size_t)chunks * ((size_t)m * n + (rowSums ? (size_t)m : 0)) * sizeof(float);
     if (chunks > 1 && workspace && workspaceBytes >= slabBytes && aligned16(workspace)) {
@@ -510,7 +533,7 @@ static int gemm_entry(const char* who, const float* A, const float* B, float* C,
 
 size_t mc_gemm_row_sums_workspace_bytes(int m, int n, int k) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
-    const int chunks = pick_gemm_chunks(m, n, k);
+    const int chunks = pick_gemm_chunks(m, n, k, true);
     return chunks > 1 ? (size_t)chunks * ((size_t)m * n + m) * sizeof(float) : 0;
 }
 

@@ -97,6 +97,7 @@ struct Dims {
     int batches;      // independent products sharing one launch (unshared layers: one per module / pixel); >= 1
     int colB;         // column offset of batch b in the B operand and in C: b * colB
     int ktabN;        // entries of the B loader's k table in LDS (set by launch_cfg; 0 = the loader decodes k arithmetically)
+    int kStep;        // distance between consecutive K tiles of one chunk (set by launch_cfg): BK, or chunks * BK when the chunks interleave
 };
 
 struct Epi {
@@ -585,7 +586,14 @@ __device__ __forceinline__ void lds_done_barrier() {
 // tiles), which fits the dense / conv weight gradients with 75-192 rows and 160-192 columns that every 4-tile shape pads by
 // 25-40 %.  The sum of an output element is (first halves of all K steps) + (second halves): a fixed order, but not the order
 // of the KQ = 1 tiles, so this tile is selected by rule only (a pure function of the shape), never by the timing autotuner.
-template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC, int NS, int EPI, int KQ>
+// MF = 1: the consumer waves multiply with v_mfma_f32_16x16x4_f32 and MT / NT count 16-row / 16-column blocks of a wave tile.
+// With 2 x 2 waves that gives workgroup tiles of 96 / 160 / 192 rows by 160 / 192 columns: a dense or first-layer weight gradient
+// whose whole output is 75-192 rows by 160-192 columns (NIN's cccp layers and conv1) is ONE tile per K chunk -- no padded matrix
+// work (the 32x32 tiles pad those products by 25-40 %) and each operand element is fetched once device-wide.  Both operands
+// k-contiguous, plain epilogue.  The k values of an 8-group go to the matrix pipe in the order of the 32x32x2 path
+// (0,4,1,5,2,6,3,7: lane group q of MFMA m takes k = 4 (q & 1) + 2 m + (q >> 1)), and the result of either instruction is one
+// k-ordered fma chain, so these tiles give the same bits as every other tile for the same K chunks.
+template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC, int NS, int EPI, int KQ, int MF = 0>
 __global__ void __launch_bounds__(2 * THREADS)
 #ifndef MC_NO_T51_CAP   // the 160-row tile sits 3-17 registers above 128 = two resident workgroups per CU: cap it (a few spills outside the K loop)
 // (not the weight-gradient kernels: their k-contiguous tiles leave LDS for one workgroup per CU, and at 128 registers they spill 300-500)
@@ -595,7 +603,9 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     static_assert(WM * WN * KQ == 4 && (KQ == 1 || KQ == 2), "4 consumer waves");
     static_assert(KQ == 1 || EPI == EPI_PLAIN, "the K-split tile has the plain epilogue only");
     static_assert(NS >= 2, "at least two tile register sets");
-    constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+    static_assert(MF == 0 || (KQ == 1 && EPI == EPI_PLAIN && AADDR::KC && BADDR::KC && BK % 8 == 0), "16x16x4 tiles: k-contiguous operands, plain epilogue");
+    constexpr int UNIT = MF ? 16 : 32;
+    constexpr int BM = UNIT * MT * WM, BN = UNIT * NT * WN;
     typedef Loader<AADDR, BM, BK, VEC> LA;
     typedef Loader<BADDR, BN, BK, VEC> LB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -619,9 +629,12 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     const int coff = b * d.colB;                      // first B / C column of this batch
     const int i0 = blockIdx.y * BM;
     const int ilim = d.Mg, jlim = coff + d.Ng;
-    const int kbeg = q * d.kChunk;
-    const int kend = min(kbeg + d.kChunk, d.Kg);
-    const int nkTile = (kend - kbeg + BK - 1) / BK;   // K steps per tile, >= 1
+    // K chunks: contiguous ranges [q * kChunk, (q + 1) * kChunk), or -- interleaved -- chunk q takes K tiles q, q + chunks, ...
+    // (d.kStep = chunks * BK), so that the workgroups running side by side read neighbouring 128-byte pieces of every operand row
+    const bool kil = d.kStep != BK;
+    const int kbeg = kil ? q * BK : q * d.kChunk;
+    const int kend = kil ? d.Kg : min(kbeg + d.kChunk, d.Kg);
+    const int nkTile = kil ? (d.Kg - kbeg + d.kStep - 1) / d.kStep : (kend - kbeg + BK - 1) / BK;   // K steps per tile, >= 1
     const int nk = nkTile * nTiles;                   // pipeline steps; barriers executed by every wave: 1 + nk
 
 #ifdef MC_ABL_STAGGER   // timing-only ablation: do the workgroups of a CU hurt each other by running in lockstep?
@@ -672,8 +685,8 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
 #ifdef MC_ABL_A_ONCE   // timing-only ablation: the A operand is fetched for a worker's first column tile only (wrong results)
                 if (ft == (int)blockIdx.x)
 #endif
-                la.fetch(ra, pa, cg, g, b, kbeg + fk * BK, kend, i0, ilim, tid);
-                lb.template fetch<TAB>(rb, pb, cg, g, b, kbeg + fk * BK, kend, fj0, jlim, tid, ktab, bcols);
+                la.fetch(ra, pa, cg, g, b, kbeg + fk * d.kStep, kend, i0, ilim, tid);
+                lb.template fetch<TAB>(rb, pb, cg, g, b, kbeg + fk * d.kStep, kend, fj0, jlim, tid, ktab, bcols);
                 if (++fk == nkTile) {
                     fk = 0;
                     ft += gridDim.x;
@@ -681,8 +694,8 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
                     if (TAB && VEC == 4) LB::prep_cols(bcols, pb, cg, g, fj0, jlim, tid);
                 }
             } else {
-                la.fetch(ra, pa, cg, g, b, kbeg + u * BK, kend, i0, ilim, tid);
-                lb.template fetch<TAB>(rb, pb, cg, g, b, kbeg + u * BK, kend, j0c, jlim, tid, ktab, bcols);
+                la.fetch(ra, pa, cg, g, b, kbeg + u * d.kStep, kend, i0, ilim, tid);
+                lb.template fetch<TAB>(rb, pb, cg, g, b, kbeg + u * d.kStep, kend, j0c, jlim, tid, ktab, bcols);
             }
         };
         auto commit = [&](const auto& la, const auto& lb, int stage) {
@@ -762,6 +775,164 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         return;
     }
 
+    if constexpr (MF == 1) {
+        // ------------------------------ consumer waves, 16x16x4 blocks ------------------------------
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int lq = lane >> 4, l15 = lane & 15, par = lq & 1;   // lq: lane group (q is this workgroup's K chunk)
+        const bool hi = lane >= 32;
+        const int wm = wave / WN, wn = wave % WN;
+        f32x4 acc[MT][NT];
+        constexpr bool SUMA = has_sum<AADDR>::value, SUMB = has_sum<BADDR>::value;
+        float rs[MT], cs[NT];
+        (void)rs; (void)cs;
+        // A K step is BK / 8 groups of 8 k's = two 16-byte chunks per row in the KC layout; lane group lq reads chunk (lq & 1) of
+        // the group whole and feeds element (lq >> 1) + 2 m of it to MFMA m.  Two fragment sets: group g + 1 (or group 0 of the next
+        // stage, complete since the previous barrier) is requested before the MFMAs of group g.
+        constexpr int GROUPS = BK / 8;
+        float4 fa[MT], fb[NT];   // ONE fragment set: a group's MFMA operands are copied out of it, then it is refilled under the MFMAs
+        auto load_group = [&](const float* cA, const float* cB, int g_) {
+#pragma unroll
+            for (int a = 0; a < MT; ++a) fa[a] = reinterpret_cast<const float4*>(cA)[(2 * g_ + par) * LA::ROWSP + (wm * MT + a) * 16 + l15];
+#pragma unroll
+            for (int b = 0; b < NT; ++b) fb[b] = reinterpret_cast<const float4*>(cB)[(2 * g_ + par) * LB::ROWSP + (wn * NT + b) * 16 + l15];
+        };
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(ep.C + q * ep.chunkStride, 0, ep.cBytes, 0x00020000);
+        lds_done_barrier();   // tiles 0 and 1 visible
+        load_group(smem, smem + LA::LDS_FLOATS, 0);
+        float a0[MT], b0[NT], a1[MT], b1[NT];   // operands of a group's first / second matrix instruction
+#pragma unroll
+        for (int a = 0; a < MT; ++a) a0[a] = hi ? fa[a].y : fa[a].x;
+#pragma unroll
+        for (int b = 0; b < NT; ++b) b0[b] = hi ? fb[b].y : fb[b].x;
+        int stage = 0;
+        for (int ct = blockIdx.x; ct < d.colTiles; ct += gridDim.x) {
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (SUMA) {
+#pragma unroll
+                for (int a = 0; a < MT; ++a) rs[a] = 0.f;
+            }
+            if constexpr (SUMB) {
+#pragma unroll
+                for (int b = 0; b < NT; ++b) cs[b] = 0.f;
+            }
+            for (int t = 0; t < nkTile; ++t) {
+                const int nstage = stage == 2 ? 0 : stage + 1;
+                const float* cA = smem + stage * STAGE;
+                const float* cB = cA + LA::LDS_FLOATS;
+                const float* nA = smem + nstage * STAGE;   // on the last K step this stage holds stale data: read, never used
+                const float* nB = nA + LA::LDS_FLOATS;
+#pragma unroll
+                for (int g_ = 0; g_ < GROUPS; ++g_) {
+                    // Pass 0 (k = 0,4,1,5 of the group's 8; operands a0 / b0 were copied out while the previous pass ran) with the
+                    // copies of pass 1's operands (elements z | w) and the k-sums issued BETWEEN its matrix instructions; then the
+                    // fragment set is refilled with the next group, which lands under pass 1, whose tail copies out the next pass 0's
+                    // operands.  The matrix pipe takes an instruction every 32 cycles; a wave's vector instructions issue in the gaps
+                    // only if they sit between the MFMAs in program order (sched_group_barrier), not in a block in front of them.
+#pragma unroll
+                    for (int a = 0; a < MT; ++a)
+#pragma unroll
+                        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[a], b0[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+                    for (int a = 0; a < MT; ++a) a1[a] = hi ? fa[a].w : fa[a].z;
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) b1[b] = hi ? fb[b].w : fb[b].z;
+                    // k-sums in the order of the 32x32 path: a lane adds its chunk's four k values in turn (lane groups 0 and 1 hold the
+                    // two chunks of the group, groups 2 and 3 copies), the two chunk sums are combined at the end of the tile
+                    if constexpr (SUMA) {
+#pragma unroll
+                        for (int a = 0; a < MT; ++a) { rs[a] += fa[a].x; rs[a] += fa[a].y; rs[a] += fa[a].z; rs[a] += fa[a].w; }
+                    }
+                    if constexpr (SUMB) {
+#pragma unroll
+                        for (int b = 0; b < NT; ++b) { cs[b] += fb[b].x; cs[b] += fb[b].y; cs[b] += fb[b].z; cs[b] += fb[b].w; }
+                    }
+#pragma unroll
+                    for (int i = 0; i < MT * NT; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // up to two VALU in its shadow
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g_ + 1 < GROUPS) load_group(cA, cB, g_ + 1);
+                    else load_group(nA, nB, 0);
+#pragma unroll
+                    for (int a = 0; a < MT; ++a)
+#pragma unroll
+                        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[a], b1[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+                    for (int a = 0; a < MT; ++a) a0[a] = hi ? fa[a].y : fa[a].x;
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) b0[b] = hi ? fb[b].y : fb[b].x;
+                    __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);   // the LDS reads first
+                    __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - (MT + NT), 0);
+#pragma unroll
+                    for (int i = 0; i < MT + NT; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                stage = nstage;
+            }
+            const int j0 = coff + col_block(ct) * BN;
+            if constexpr (SUMA) {
+                if (ep.sumOut) {
+#pragma unroll
+                    for (int a = 0; a < MT; ++a) {
+                        const float v = rs[a] + __shfl_xor(rs[a], 16);
+                        const int i = i0 + (wm * MT + a) * 16 + l15;
+                        if (ct == 0 && wn == 0 && lq == 0 && i < ilim) ep.sumOut[q * ep.sumStride + i + g * ep.rowG] = ep.sumAlpha * v;
+                    }
+                }
+            }
+            if constexpr (SUMB) {
+                if (ep.sumOut) {
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) {
+                        const float v = cs[b] + __shfl_xor(cs[b], 16);
+                        const int j = j0 + (wn * NT + b) * 16 + l15;
+                        if (blockIdx.y == 0 && wm == 0 && lq == 0 && j < jlim) ep.sumOut[q * ep.sumStride + j + g * ep.colG] = ep.sumAlpha * v;
+                    }
+                }
+            }
+            // store: C/D map of the 16x16 block: col = lane & 15, row = 4 * (lane >> 4) + r.  Branch-free through the chunk's descriptor.
+            const unsigned ldcB = (unsigned)ep.ldc * 4u;
+            const bool relu = ep.act == MC_NEURON_RELU;
+            // the row / column terms below do not change from tile to tile; opaque copies of the lane coordinates keep the compiler
+            // from hoisting a register per (block, row) of them out of the tile loop (spills at 256 registers otherwise)
+            int lqq = lq, lcc = l15;
+            asm volatile("" : "+v"(lqq), "+v"(lcc));
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                __builtin_amdgcn_sched_barrier(0);   // a block row at a time
+                const int rl0 = (wm * MT + a) * 16 + 4 * lqq;
+                const int iB = i0 + rl0;
+                const float4 bq = *reinterpret_cast<const float4*>(&smem[3 * STAGE + rl0]);
+                const float bia[4] = {bq.x, bq.y, bq.z, bq.w};
+                const unsigned rowB = (unsigned)(iB + g * ep.rowG) * ldcB;
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    const int j = j0 + (wn * NT + b) * 16 + lcc;
+                    const bool jok = j < jlim;
+                    const unsigned colB = (unsigned)(j + g * ep.colG) * 4u;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned off = (jok & (iB + r < ilim)) ? rowB + (unsigned)r * ldcB + colB : OOB;
+                        float v = ep.alpha * acc[a][b][r] + bia[r];
+                        v = (relu & (v < 0.f)) ? 0.f : v;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, off, 0, 0);
+                    }
+                }
+            }
+        }
+        return;
+    }
     // ------------------------------ consumer waves ------------------------------
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1070,15 +1241,15 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
 // ---------------------------------------------------------------------------------
 // Host-side launch helpers
 // ---------------------------------------------------------------------------------
-template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC, int EPI, int NS = MC_NS, int KQ = 1>
+template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC, int EPI, int NS = MC_NS, int KQ = 1, int MF = 0>
 int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const ConvG& cg, const Dims& d0,
                const Epi& ep, int chunks, hipStream_t st) {
-    constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+    constexpr int BM = (MF ? 16 : 32) * MT * WM, BN = (MF ? 16 : 32) * NT * WN;
     typedef Loader<AADDR, BM, BK, VEC> LA;
     typedef Loader<BADDR, BN, BK, VEC> LB;
     constexpr size_t ldsTile = (3 * (LA::LDS_FLOATS + LB::LDS_FLOATS) + BM) * sizeof(float);   // three stages + the tile's bias column
     static_assert(ldsTile <= 160 * 1024, "LDS budget");
-    auto kern = mc_igemm<AADDR, BADDR, MT, NT, WM, WN, BK, VEC, NS, EPI, KQ>;
+    auto kern = mc_igemm<AADDR, BADDR, MT, NT, WM, WN, BK, VEC, NS, EPI, KQ, MF>;
     Dims d = d0;
     // the B loader's k table (8 bytes per k, padded to whole K tiles + one tile of slack for the k tail of a chunk)
     static const bool noktab = getenv("MC_IGEMM_NOKTAB") != nullptr;
@@ -1087,6 +1258,8 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
         const int n = (ceil_div(d.Kg, BK) + 1) * BK;
         if (ldsTile + (size_t)n * 8 <= 160 * 1024) d.ktabN = n;
     }
+    static const bool kInterleave = getenv("MC_IGEMM_KINTERLEAVE") != nullptr;   // experiment: interleaved K chunks for the k-contiguous products
+    d.kStep = (kInterleave && AADDR::KC && BADDR::KC && chunks > 1 && d.kChunk % BK == 0 && d.Kg % BK == 0) ? chunks * BK : BK;
     const size_t lds = ldsTile + (size_t)d.ktabN * 8;
     constexpr size_t ldsMax = has_ktab<BADDR>::value ? (ldsTile + (size_t)(KTAB_MAX + 2 * BK) * 8 <= 160 * 1024 ? ldsTile + (size_t)(KTAB_MAX + 2 * BK) * 8 : 160 * 1024) : ldsTile;
     // per-device state of this instantiation (a function attribute belongs to the device's own code object)
@@ -1121,8 +1294,8 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
     static const bool noswz = getenv("MC_IGEMM_NOSWZ") != nullptr;
     d.xcdSwizzle = (d.colTiles % 8 == 0 && grid.x % 8 == 0 && d.colTiles >= 16 && !noswz) ? 1 : 0;
     if (g_describeBuf) {   // dry run (mc_describe_*): which instantiation and grid this shape gets right now
-        snprintf(g_describeBuf, (size_t)g_describeLen, "mc_igemm<%s, %s, %d, %d, %d, %d, %d, %d, %d, %d, %d> grid=(%u,%u,%u) tile %dx%d", AADDR::tag(),
-                 BADDR::tag(), MT, NT, WM, WN, BK, VEC, NS, EPI, KQ, grid.x, grid.y, grid.z, BM, BN);
+        snprintf(g_describeBuf, (size_t)g_describeLen, "mc_igemm<%s, %s, %d, %d, %d, %d, %d, %d, %d, %d, %d%s> grid=(%u,%u,%u) tile %dx%d", AADDR::tag(),
+                 BADDR::tag(), MT, NT, WM, WN, BK, VEC, NS, EPI, KQ, MF ? ", 1" : "", grid.x, grid.y, grid.z, BM, BN);
         return MC_OK;
     }
     hipLaunchKernelGGL(kern, grid, dim3(2 * THREADS), lds, st, pa, pb, cg, d, ep);
@@ -1139,15 +1312,21 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
 // MC_IGEMM_AUTOTUNE=0, report with =2).  Every tile adds the k terms of an output element in the same
 // order, so the choice never changes a result bit; the split-K chunk count, which would, is not tuned.
 // ---------------------------------------------------------------------------------
-enum { T11, T21, T31, T51, T23, T32, T14, T24, NTILES, T33K = NTILES };   // NTILES: the tiles the autotuner may pick among
-static const char* const kTileName[NTILES + 1] = {"32x128", "64x128", "96x128", "160x128", "128x192", "192x128", "128x32", "128x64", "96x192k2"};
+// M56 .. M33: the 16x16x4 tiles (2 x 2 waves of MT x NT 16-blocks; both operands k-contiguous, plain epilogue only)
+enum { T11, T21, T31, T51, T23, T32, T14, T24, M56, M35, M66, M36, M33, NTILES, T33K = NTILES };   // NTILES: the tiles the autotuner may pick among
+static const char* const kTileName[NTILES + 1] = {"32x128", "64x128", "96x128", "160x128", "128x192", "192x128", "128x32", "128x64",
+                                                  "160x192m", "96x160m", "192x192m", "96x192m", "96x96m", "96x192k2"};
+inline bool is_mf_tile(int t) { return t >= M56 && t <= M33; }
 
 // LDS footprint of a tile (three stages + the bias column): a k-contiguous build with a longer K tile (MC_BK_KC=64) keeps
 // only the tiles that still fit 160 KB; launch_tile maps the others to the nearest one that does.
-template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC>
+template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC, int UNIT = 32>
 constexpr bool tile_fits() {
-    return (3 * (size_t)(Loader<AADDR, 32 * MT * WM, BK, VEC>::LDS_FLOATS + Loader<BADDR, 32 * NT * WN, BK, VEC>::LDS_FLOATS) + 32 * MT * WM) * sizeof(float) <= 160 * 1024;
+    return (3 * (size_t)(Loader<AADDR, UNIT * MT * WM, BK, VEC>::LDS_FLOATS + Loader<BADDR, UNIT * NT * WN, BK, VEC>::LDS_FLOATS) + UNIT * MT * WM) * sizeof(float) <= 160 * 1024;
 }
+// the 16x16x4 tiles exist for these products only
+template <class AADDR, class BADDR, int BK, int EPI>
+constexpr bool mf_ok() { return AADDR::KC && BADDR::KC && BK % 8 == 0 && EPI == EPI_PLAIN; }
 
 template <class AADDR, class BADDR, int BK, int VEC, int EPI>
 int launch_tile(int tile, const typename AADDR::P& pa, const typename BADDR::P& pb, const ConvG& cg, const Dims& d, const Epi& ep,
@@ -1158,6 +1337,23 @@ int launch_tile(int tile, const typename AADDR::P& pa, const typename BADDR::P& 
     if constexpr (!tile_fits<AADDR, BADDR, 5, 1, 1, 4, BK, VEC>()) tile = tile == T51 ? T21 : tile;
     if constexpr (!tile_fits<AADDR, BADDR, 2, 3, 2, 2, BK, VEC>()) tile = tile == T23 ? T21 : tile;
     if constexpr (!tile_fits<AADDR, BADDR, 3, 2, 2, 2, BK, VEC>()) tile = tile == T32 ? T21 : tile;
+    if constexpr (mf_ok<AADDR, BADDR, BK, EPI>()) {
+        switch (tile) {
+#define MC_MF_CASE(T, MT_, NT_)                                                                                                       \
+            case T:                                                                                                                   \
+                if constexpr (tile_fits<AADDR, BADDR, MT_, NT_, 2, 2, BK, VEC, 16>())                                                 \
+                    return launch_cfg<AADDR, BADDR, MT_, NT_, 2, 2, BK, VEC, EPI, MC_NS, 1, 1>(pa, pb, cg, d, ep, chunks, st);            \
+                break;
+            MC_MF_CASE(M56, 5, 6)
+            MC_MF_CASE(M35, 3, 5)
+            MC_MF_CASE(M66, 6, 6)
+            MC_MF_CASE(M36, 3, 6)
+            MC_MF_CASE(M33, 3, 3)
+#undef MC_MF_CASE
+            default: break;
+        }
+    }
+    if (is_mf_tile(tile)) tile = T31;   // asked for a product that has no 16x16x4 form
     switch (tile) {
         case T11: return launch_cfg<AADDR, BADDR, 1, 1, 1, 4, BK, VEC, EPI>(pa, pb, cg, d, ep, chunks, st);
         case T21: return launch_cfg<AADDR, BADDR, 2, 1, 1, 4, BK, VEC, EPI>(pa, pb, cg, d, ep, chunks, st);
@@ -1193,11 +1389,23 @@ int launch_tile(int tile, const typename AADDR::P& pa, const typename BADDR::P& 
 // strip per consumer wave) win almost everywhere; exactly 160 rows (NIN cccp1 / cccp2) take one 160-row tile so
 // the big operand is read once; 192-column tiles (2x2 waves, 3 strips each) when they cut the padding of the
 // column extent (F = 192 weight gradients: 256 -> 192).
-static const int kRowsOf[NTILES + 1] = {32, 64, 96, 160, 128, 192, 128, 128, 96}, kColsOf[NTILES + 1] = {128, 128, 128, 128, 192, 128, 32, 64, 192};
+static const int kRowsOf[NTILES + 1] = {32, 64, 96, 160, 128, 192, 128, 128, 160, 96, 192, 96, 96, 96},
+                 kColsOf[NTILES + 1] = {128, 128, 128, 128, 192, 128, 32, 64, 192, 160, 192, 192, 96, 192};
 inline int heuristic_tile4(const Dims& d, int chunks);
+// The 16x16x4 tile for a product whose WHOLE output is one such tile (75-192 rows by 129-192 columns: the dense weight gradients of
+// the cccp layers, the first conv layer's weight gradient), or -1.  A pure function of the extents: chunk plans are made with it.
+inline int whole_output_mf_tile(int Mg, int Ng) {
+    if (!mf_whole_output(Mg, Ng)) return -1;
+    if (Ng <= 160 && Mg <= 96) return M35;
+    return Mg <= 96 ? M36 : Mg <= 160 ? M56 : M66;
+}
 // kqOk: the call site has the 96 x 192 K-split tile (long-k products).  It is taken when it cuts the padded work of the
 // 4-tile rule's pick by 15 % or more -- decided from the extents alone, see the kernel's comment.
-inline int heuristic_tile(const Dims& d, int chunks, bool kqOk = false) {
+inline int heuristic_tile(const Dims& d, int chunks, bool kqOk = false, bool mfOk = false) {
+    if (mfOk && d.batches == 1) {
+        const int m = whole_output_mf_tile(d.Mg, d.Ng);
+        if (m >= 0) return m;
+    }
     const int t = heuristic_tile4(d, chunks);
 #ifndef MC_IGEMM_KQ_TILE
     // Measured on MI355X (NIN weight gradients, tools/build_variant.sh kq -DMC_IGEMM_KQ_TILE): the tile removes the padding
@@ -1240,11 +1448,15 @@ int launch_rows_cols_epi(const typename AADDR::P& pa, const typename BADDR::P& p
     // tuning knob (benchmarks only): MC_IGEMM_TILE="MT,NT" forces the wave tile
     static const char* forced = getenv("MC_IGEMM_TILE");
     if (forced && forced[0] && forced[1] == ',') {
-        static const int map[9][3] = {{1, 1, T11}, {2, 1, T21}, {3, 1, T31}, {5, 1, T51}, {2, 3, T23}, {3, 2, T32}, {4, 0, T14}, {4, 1, T24}, {3, 3, T33K}};
+        static const int map[14][3] = {{1, 1, T11}, {2, 1, T21}, {3, 1, T31}, {5, 1, T51}, {2, 3, T23}, {3, 2, T32}, {4, 0, T14}, {4, 1, T24}, {3, 3, T33K},
+                                       {5, 6, M56}, {3, 5, M35}, {6, 6, M66}, {3, 6, M36}, {9, 9, M33}};
         for (auto& m : map)
             if (forced[0] - '0' == m[0] && forced[2] - '0' == m[1]) return launch_tile<AADDR, BADDR, BK, VEC, EPI>(m[2], pa, pb, cg, d, ep, chunks, st);
     }
-    const int rule = heuristic_tile(d, chunks, BK == 32 && EPI == EPI_PLAIN && !ep.sumOut);   // (the K-split tile has no k-sums)
+    constexpr bool MFOK = mf_ok<AADDR, BADDR, BK, EPI>();
+    static const bool nomf = getenv("MC_IGEMM_NOMF") != nullptr;   // A/B switch: without the 16x16x4 tiles (and their chunk plans)
+    const bool mfNow = MFOK && !nomf && !ep.bitsOut && !ep.bitsIn;
+    const int rule = heuristic_tile(d, chunks, BK == 32 && EPI == EPI_PLAIN && !ep.sumOut, mfNow);   // (the K-split tile has no k-sums)
     if (rule == T33K) return launch_tile<AADDR, BADDR, BK, VEC, EPI>(rule, pa, pb, cg, d, ep, chunks, st);   // by rule only: its sum order is its own
     static const char* at = getenv("MC_IGEMM_AUTOTUNE");
     static const int mode = at ? atoi(at) : 1;
@@ -1277,6 +1489,7 @@ int launch_rows_cols_epi(const typename AADDR::P& pa, const typename BADDR::P& p
         // skip tiles that would compute more than 4x the needed rows (a 160-row tile for a 10-row product)
         if (t != rule && (long)ceil_div(d.Mg, kRowsOf[t]) * kRowsOf[t] > 4L * ((d.Mg + 31) / 32 * 32)) continue;
         if ((t == T14 || t == T24) && d.Ng > 64) continue;   // the narrow tile only where 128 columns are mostly padding
+        if (is_mf_tile(t) && (!mfNow || d.batches != 1 || d.Ng <= 64 || d.Mg <= 32)) continue;   // 16x16x4 tiles: k-contiguous products with a wide output
         int rc = launch_tile<AADDR, BADDR, BK, VEC, EPI>(t, pa, pb, cg, d, ep, chunks, st);   // warm (and validates the launch)
         if (rc != MC_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
         (void)hipEventRecord(e0, st);

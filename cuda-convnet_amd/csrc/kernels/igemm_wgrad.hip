@@ -46,7 +46,8 @@ int conv_weight_grad_plan(int N, int C, int F, int fs, int M, int groups, int* k
     const long K = (long)M * N;
     Dims d{rows, fpg, (int)K, (int)K, groups, 0, 0, 1, 0};
     // the tile the static rule would take for a grid that fills the device
-    const int t = heuristic_tile(d, ceil_div(num_cus(), (long)ceil_div(rows, 128) * ceil_div(fpg, 128) * groups), true);
+    static const bool nomf = getenv("MC_IGEMM_NOMF") != nullptr;
+    const int t = heuristic_tile(d, ceil_div(num_cus(), (long)ceil_div(rows, 128) * ceil_div(fpg, 128) * groups), true, !nomf);
     const long tiles = (long)ceil_div(rows, kRowsOf[t]) * ceil_div(fpg, kColsOf[t]) * groups;
     long chunks = num_cus() / tiles;
     if (chunks < 1) chunks = 1;

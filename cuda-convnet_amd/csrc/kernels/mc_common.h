@@ -35,4 +35,8 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15)
 
 int num_cus();
 
+// A k-contiguous product whose WHOLE output is one 16x16x4 workgroup tile (igemm_core.h, MF tiles): 65-192 rows by 129-192
+// columns.  Chunk plans are made with it, so it is a pure function of the extents.
+inline bool mf_whole_output(int rows, int cols) { return rows > 64 && rows <= 192 && cols > 128 && cols <= 192; }
+
 }  // namespace mc

@@ -153,10 +153,19 @@ class GoldenNet(object):
         l = self.layers[idx]
         return bool(l["gradConsumer"]) or any(self._grad_consumer(i) for i in l.get("inputs", []))
 
-    def bprop(self, train=True, gc=False):
+    def bprop(self, train=True, gc=False, decide=None):
         """Fills self.grads (activity gradients) and self.wgrads / self.bgrads (already scaled by
-        eps / numCases as the reference does, layer.cu:491-523; scale 1 under PASS_GC)."""
+        eps / numCases as the reference does, layer.cu:491-523; scale 1 under PASS_GC).
+
+        decide (tests only): dict layer name -> that layer's forward output as ANOTHER implementation computed it.  The
+        two discontinuous decisions of back-propagation -- a relu's gradient mask (output > 0, neuron.cuh:166-178) and a
+        max-pool's equality routing (conv_util.cu:1567) -- are then taken from those values instead of this net's own, so
+        that a pre-activation within rounding of zero, or two window entries within rounding of each other, cannot make
+        two correct implementations disagree by O(1) in single gradient entries.  The caller checks that the supplied
+        values agree with this net's forward pass and counts the decisions that differ (self.flips)."""
         L, A, N = self.layers, self.acts, self.N
+        decide = decide or {}
+        self.flips = {}
         Ng = self.global_cases if getattr(self, 'global_cases', 0) else N * self.world   # data parallel: cases of the GLOBAL minibatch
         g = {}
         self.wgrads, self.bgrads = {}, {}
@@ -241,11 +250,20 @@ class GoldenNet(object):
                 nt, params = l["neuron"]["type"], l["neuron"]["params"]
                 if nt == "dropout":
                     send(inp[0], G.neuron_bwd("dropout", params, v, A[name], ins[0], train=(train and not gc), mask=self.aux.get(name)))
+                elif nt == "relu" and name in decide:
+                    theirs = decide[name]
+                    self.flips[name] = np.flatnonzero((theirs > 0) != (A[name] > 0))
+                    send(inp[0], G.neuron_bwd(nt, params, v, theirs, ins[0]))
                 else:
                     send(inp[0], G.neuron_bwd(nt, params, v, A[name], ins[0]))
             elif t == "pool":
                 geo = (N, l["channels"], l["imgSize"], l["sizeX"], l["start"], l["stride"], l["outputsX"])
-                if l["pool"] == "max":
+                if l["pool"] == "max" and name in decide and L[inp[0]]["name"] in decide:
+                    x2, y2 = decide[L[inp[0]]["name"]], decide[name]
+                    mine, theirs = G.max_undo(ins[0], np.ones_like(v), A[name], *geo), G.max_undo(x2, np.ones_like(v), y2, *geo)
+                    self.flips[name] = np.flatnonzero(mine != theirs)          # input pixels routed to differently
+                    send(inp[0], G.max_undo(x2, v, y2, *geo))
+                elif l["pool"] == "max":
                     send(inp[0], G.max_undo(ins[0], v, A[name], *geo))
                 else:
                     send(inp[0], G.avg_undo(v, *geo))

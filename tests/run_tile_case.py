@@ -41,4 +41,20 @@ d1, d2 = nans(mm, nn), nans(mm, nn)
 m.call("mc_gemm_relu_grad", ptr(V), ptr(g), ptr(d1), mm, nn, 96, 1, 0, mm, nn, nn, 0.0, 1.0, ptr(y), nn, None, 0, None)
 m.call("mc_gemm_relu_grad_bits", ptr(V), ptr(g), ptr(d2), mm, nn, 96, 1, 0, mm, nn, nn, 1.0, ptr(bits), None)
 res["dense_bwd_mask"], res["dense_bwd_bits"] = host(d1), host(d2)
+# weight-gradient orientation (both operands k-contiguous: the products the 16x16x4 tiles exist for), split K with the shape's own
+# chunk plan and the bias gradient as a by-product: a dense one whose whole output is one 160x192 tile, one of 96x160, and a
+# first-layer conv weight gradient (75 rows = 3 channels x 5x5 taps, 192 filters)
+for tag, (wm_, wn_, wk_) in (("wg160x192", (160, 192, 4096)), ("wg96x160", (96, 160, 3072)), ("wg192x192", (192, 192, 2048)), ("wg10x192", (10, 192, 2048))):
+    Ag, Bg = dev(rng.standard_normal((wm_, wk_))), dev(rng.standard_normal((wn_, wk_)))
+    wsb = m.lib().mc_gemm_row_sums_workspace_bytes(wm_, wn_, wk_)
+    ws, cg_, rs_ = nans(max(1, wsb // 4)), nans(wm_, wn_), nans(wm_)
+    m.call("mc_gemm_row_sums", ptr(Ag), ptr(Bg), ptr(cg_), wm_, wn_, wk_, wk_, wk_, wn_, 0.0, 0.5, ptr(rs_), 0.25, ptr(ws), wsb, None)
+    res[tag], res[tag + "_sums"] = host(cg_), host(rs_)
+N1, C1, H1, fs1, F1, pad1 = 32, 3, 12, 5, 192, 2
+geo1 = (N1, C1, H1, H1, F1, fs1, -pad1, 1, H1, H1, 1)
+img1, hid1 = dev(rng.standard_normal((C1 * H1 * H1, N1))), dev(rng.standard_normal((F1 * H1 * H1, N1)))
+wsb = m.lib().mc_conv_weight_grad_bias_workspace_bytes(N1, C1, F1, fs1, H1 * H1, 1)
+ws, dw1, db1 = nans(max(1, wsb // 4)), nans(C1 * fs1 * fs1, F1), nans(F1)
+m.call("mc_conv_weight_grad_bias", ptr(img1), ptr(hid1), ptr(dw1), ptr(db1), *geo1, 0.0, 1.0, 0.5, ptr(ws), wsb, None)
+res["conv1_wgrad"], res["conv1_bgrad"] = host(dw1), host(db1)
 np.savez(sys.argv[1], **res)

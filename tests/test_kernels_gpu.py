@@ -695,7 +695,8 @@ def test_conv_relu_bits(N, C, H, fs, F, pad):
 def test_tile_choice_never_changes_a_bit():
     """The tile autotuner picks by timing, inside a library that promises run-to-run identical results: that is sound only if
     every workgroup tile adds the k terms of an output element in the same order.  One conv triple and dense products under
-    each of the eight forced tiles (MC_IGEMM_TILE, autotune off) and under the autotuner: all outputs bit-identical."""
+    each of the forced tiles (MC_IGEMM_TILE, autotune off) and under the autotuner: all outputs bit-identical -- including the
+    16x16x4 tiles, whose matrix instruction takes four k values at a time in the k order of the 32x32x2 tiles (igemm_core.h)."""
     import os
     import subprocess
     import sys
@@ -703,7 +704,9 @@ def test_tile_choice_never_changes_a_bit():
     here = os.path.dirname(os.path.abspath(__file__))
     tmp = tempfile.mkdtemp(prefix="tiles_")
     runs = {}
-    for tile in ["1,1", "2,1", "3,1", "5,1", "2,3", "3,2", "4,0", "4,1", "auto"]:
+    # ("5,6" ... "9,9": the 16x16x4 tiles, 160x192 / 96x160 / 192x192 / 96x192 / 96x96, which exist for products with both operands
+    # k-contiguous -- the weight gradients -- and fall back to 96x128 elsewhere)
+    for tile in ["1,1", "2,1", "3,1", "5,1", "2,3", "3,2", "4,0", "4,1", "5,6", "3,5", "6,6", "3,6", "9,9", "auto"]:
         env = dict(os.environ)
         if tile == "auto":
             env.pop("MC_IGEMM_TILE", None)

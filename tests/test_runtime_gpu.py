@@ -98,8 +98,11 @@ CASES = [("gc-small", 128 + 70, 128, "max"), ("nin-tiny", 128 + 70, 128, "max"),
          # with seed 42 one case's p[label] underflows to 0 and the cost is inf on both sides
          ("gc", 64 + 22, 64, "max", 0.0, 7),
          # THE net the headline number is quoted on, with its shipped parameters (NIN/cifar-10_def + cifar-10_params: epsW = 1,
-         # wc = 1e-5, coeff = 0.1), full size, a 16-case minibatch and a 6-case tail (the oracle needs ~20 s for these 22 cases)
-         ("nin", 16 + 6, 16, "max")]
+         # wc = 1e-5, coeff = 0.1), full size, a 16-case minibatch and a 6-case tail.  Frobenius norm: conv1's relu has 3 x 10^6 units
+         # per 16 cases and meets a pre-activation within fp32 rounding of zero about once per step, which moves single entries of
+         # conv1's gradient only (every other tensor agrees to 6e-6 at max error); the strict, flip-counting comparison of this net
+         # is test_one_step_strict_whatever_the_ties below
+         ("nin", 16 + 6, 16, "l2")]
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(str(x) for x in c))
@@ -139,6 +142,68 @@ def test_train_step_matches_oracle(case):
             bad.append(row)
     assert not bad, bad
     print("worst weight rel err", worst)
+
+
+# (net, minibatch, init_w, weight seed): one training step each, at the strict metric, for EVERY seed -- including the ones the
+# multi-minibatch cases above avoid because a max-pool or relu decision flips (conv-local 42 / 44, imagenet 42) -- and for NIN
+# cifar-10 with its shipped parameters, whose first relu has 3 x 10^6 units per 16 cases and meets a pre-activation within
+# rounding of zero about once per step.
+DECISION_CASES = [("nin", 16, 0.0, 42), ("nin", 16, 0.0, 43), ("conv-local", 128, 0.05, 42), ("conv-local", 128, 0.05, 43), ("conv-local", 128, 0.05, 44),
+                  ("imagenet", 8, 0.02, 42), ("80sec", 128, 0.0, 42)]
+
+
+@pytest.mark.parametrize("case", DECISION_CASES, ids=lambda c: "-".join(str(x) for x in c))
+def test_one_step_strict_whatever_the_ties(case):
+    """The flip-tolerant strict metric.  Back-propagation has two discontinuous decisions: a relu's gradient mask (output > 0)
+    and a max-pool's equality routing.  When a pre-activation lies within fp32 rounding of zero, or a window's two largest
+    entries within rounding of each other, two correct implementations may decide differently and single gradient entries
+    move by O(1); the forward values agree to 1e-6 all the same.  So: the GPU's forward outputs of every relu and max-pool
+    layer are read back, checked against the oracle's forward pass (max error 1e-4 of the RMS), and handed to the oracle's
+    backward pass, which takes those two decisions from them (GoldenNet.bprop(decide=...)).  The decisions that differ are
+    COUNTED (at most 10 per step, each at a relu input within 1e-5 of zero relative to the layer's RMS, or a routing change)
+    and everything downstream is then compared at the strict tolerance: weights 1e-4, increments 2e-4 of their RMS."""
+    net_name, mini, init_w, seed = case
+    sys.path.insert(0, HERE)
+    from run_net_step import make_masks
+    layers, dims, classes = modelutil.load_net(net_name, seed=seed, init_w=init_w)
+    relus = [l["name"] for l in layers if l["type"] == "neuron" and l["neuron"]["type"] == "relu"]
+    pools = [l["name"] for l in layers if l["type"] == "pool" and l["pool"] == "max"]
+    got, _ = run_child(net=net_name, cases=mini, mini=mini, init_w=init_w, seed=seed, acts=",".join(relus + pools))
+    data = modelutil.synthetic_batch(dims, classes, mini)
+    net = GoldenNet(layers)
+    masks = make_masks(layers, mini, mini)
+    names = [nm for nm, _ in modelutil.dropout_layers(layers)]
+    costs = net.fprop(data, train=True, masks=dict(zip(names, masks[0])))
+    np.testing.assert_allclose(got["cost:logprob"][0], costs["logprob"][0], rtol=2e-4, atol=1e-3)
+    decide = {}
+    for nm in relus + pools:
+        assert rel_rms(got["acts:" + nm], net.acts[nm]) < 1e-4, nm          # the forward pass agrees everywhere
+        decide[nm] = got["acts:" + nm]
+    net.bprop(train=True, decide=decide)
+    by = dict((l["name"], l) for l in layers)
+    flips = 0
+    for nm, idx in net.flips.items():
+        flips += len(idx)
+        if len(idx) and by[nm]["type"] == "neuron":      # a flipped relu sits at a pre-activation within rounding of zero
+            pre = net.acts[layers[by[nm]["inputs"][0]]["name"]]
+            assert np.abs(pre.reshape(-1)[idx]).max() < 1e-5 * float(np.sqrt((pre.astype(np.float64) ** 2).mean())), nm
+        print("%-16s decisions that differ: %d" % (nm, len(idx)))
+    assert flips <= 10, net.flips
+    net.update()
+    bad = []
+    for l in layers:
+        if "weights" not in l:
+            continue
+        rows = [("W:%s:%d" % (l["name"], i), net.W[(l["name"], i)], "Winc:%s:%d" % (l["name"], i), net.Winc.get((l["name"], i)))
+                for i in range(len(l["weights"])) if isinstance(net.W[(l["name"], i)], np.ndarray)]
+        rows.append(("B:" + l["name"], net.B[l["name"]], "Binc:" + l["name"], net.Binc[l["name"]]))
+        for kw, w, ki, inc in rows:
+            e1, e2 = rel_rms(got[kw], w), rel_rms(got[ki], inc)
+            print("%-20s W %.2e  inc %.2e" % (kw, e1, e2))
+            if not (e1 < 1e-4 and e2 < 2e-4):
+                bad.append((kw, e1, e2))
+    assert not bad, bad
+    print("decisions that differed:", flips)
 
 
 @pytest.mark.parametrize("net_name,cases,mini", [("80sec", 6 * 32 + 7, 32), ("example-small", 5 * 16 + 3, 16), ("conv-local", 5 * 16, 16)])
