@@ -86,13 +86,13 @@ __global__ void __launch_bounds__(256) k_splitk_reduce_tall(const float4* __rest
     const size_t e = (size_t)blockIdx.x * 16 + cg;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e < total4) {
-        int q = qg;   // eight slabs' loads in flight, added in slab order (same bits as one at a time)
-        for (; q + 7 * 16 < chunks; q += 8 * 16) {
-            float4 x[8];
+        int q = qg;   // sixteen slabs' loads in flight, added in slab order (same bits as one at a time)
+        for (; q + 15 * 16 < chunks; q += 16 * 16) {
+            float4 x[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = slabs[(size_t)(q + 16 * u) * total4 + e];
+            for (int u = 0; u < 16; ++u) x[u] = slabs[(size_t)(q + 16 * u) * total4 + e];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+            for (int u = 0; u < 16; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
         }
         for (; q < chunks; q += 16) {
             const float4 x = slabs[(size_t)q * total4 + e];

@@ -805,15 +805,15 @@ __global__ void __launch_bounds__(256) k_sum_cols4_tall(const float4* __restrict
     const int c = blk * 16 + cg;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < cols4) {
-        // eight rows' loads in flight per thread, added in row order (the order of the plain loop: same bits); with one load at
+        // sixteen rows' loads in flight per thread, added in row order (the order of the plain loop: same bits); with one load at
         // a time the 16 dependent round trips of a 256-slab split-K reduction were the whole kernel
         int r = rg;
-        for (; r + 7 * 16 < rows; r += 8 * 16) {
-            float4 x[8];
+        for (; r + 15 * 16 < rows; r += 16 * 16) {
+            float4 x[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = v[(size_t)(r + 16 * u) * cols4 + c];
+            for (int u = 0; u < 16; ++u) x[u] = v[(size_t)(r + 16 * u) * cols4 + c];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+            for (int u = 0; u < 16; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
         }
         for (; r < rows; r += 16) {
             const float4 x = v[(size_t)r * cols4 + c];

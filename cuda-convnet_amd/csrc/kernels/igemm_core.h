@@ -120,7 +120,7 @@ struct Epi {
     unsigned wBytes;          // extent of the bit matrix in bytes
     // Sum of one operand over k, a by-product of kernels whose A or B loader is tagged SUM (weight gradients: the operand is
     // the layer's output gradient, its sum over k the bias gradient): chunk q writes sumAlpha * sum_k op(k, x) to
-    // sumOut[q * sumStride + x + g * (rowG | colG)].  Nullable.  Each lane adds the k values it feeds to the MFMAs anyway,
+    // sumOut[q * sumStride + x + g * (rowG | colG)].  Nullable.  Formed by the producer waves from the chunks they stage (Loader::add_sums),
     // in k order, so the result does not depend on the tile shape.
     float* sumOut;
     long sumStride;
@@ -401,7 +401,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsi
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
 }
 
-template <class ADDR, int ROWS, int BK, int VEC>
+// PERM (k-contiguous operands of the 16x16x4 tiles): the four k values of a 16-byte chunk are stored as (k0, k2 | k1, k3) in even
+// chunks of a row and (k1, k3 | k0, k2) in odd ones, so that a consumer lane reads the two values it feeds to a group's two matrix
+// instructions with ONE ds_read_b64 and no select (see the MF consumer).
+template <class ADDR, int ROWS, int BK, int VEC, bool PERM = false>
 struct Loader {
     typedef typename ADDR::P P;
     static constexpr bool KC = ADDR::KC;
@@ -547,6 +550,30 @@ struct Loader {
         }
     }
 
+    // k-sums of a k-contiguous operand (weight gradients: the operand is the layer's output gradient, its sum over k the bias
+    // gradient): each producer thread adds the four k values of its chunks, in k order, to one partial per chunk slot; a row's
+    // BK / 4 partials sit in consecutive lanes and are combined when the K loop is over (sum_rows).  The order depends on BK and on
+    // the K chunks only, not on the tile.  The producers have the time: the consumers' matrix instructions do not overlap with
+    // their own vector instructions (tools/census/mfma16_probe.hip: 2 VALU per 16x16x4 MFMA cost 6.8 of its 32 cycles).
+    __device__ __forceinline__ void add_sums(float* ps) const {
+        static_assert(KC, "k-sums come with k-contiguous operands");
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) { ps[it] += r[it].x; ps[it] += r[it].y; ps[it] += r[it].z; ps[it] += r[it].w; }
+    }
+    // out[x0 + row] = alpha * (sum of the row's partials), rows < xlim; every lane of the wave must call
+    __device__ static __forceinline__ void sum_rows(const float* ps, float* out, float alpha, int x0, int xlim, int tid) {
+        static_assert(BK / 4 == 8, "a row's partials are combined over 8 consecutive lanes");
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) {
+            float v = ps[it];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            const int c = tid + it * THREADS;
+            const int x = x0 + c / (BK / 4);
+            if ((CHUNKS % THREADS == 0 || c < CHUNKS) && (c % (BK / 4)) == 0 && x < xlim) out[x] = alpha * v;
+        }
+    }
     __device__ __forceinline__ void commit(float* lds, int tid) const {
 #ifdef MC_ABL_NOCOMMIT
         return;
@@ -557,7 +584,15 @@ struct Loader {
             const int c = tid + it * THREADS;
             if (CHUNKS % THREADS == 0 || c < CHUNKS) {
                 if (KC) {
-                    l4[(c % (BK / 4)) * ROWSP + c / (BK / 4)] = r[it];
+                    float4 v = r[it];
+                    if constexpr (PERM) {   // component-wise selects (as one ternary over the struct the compiler branches, inside the producers' K loop)
+                        const bool odd = (c & 1) != 0;   // = tid & 1: THREADS is even
+                        v.x = odd ? r[it].y : r[it].x;
+                        v.y = odd ? r[it].w : r[it].z;
+                        v.z = odd ? r[it].x : r[it].y;
+                        v.w = odd ? r[it].z : r[it].w;
+                    }
+                    l4[(c % (BK / 4)) * ROWSP + c / (BK / 4)] = v;
                 } else {
                     l4[c] = r[it];  // [dk][dx/4] == linear chunk order
                 }
@@ -606,8 +641,8 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     static_assert(MF == 0 || (KQ == 1 && EPI == EPI_PLAIN && AADDR::KC && BADDR::KC && BK % 8 == 0), "16x16x4 tiles: k-contiguous operands, plain epilogue");
     constexpr int UNIT = MF ? 16 : 32;
     constexpr int BM = UNIT * MT * WM, BN = UNIT * NT * WN;
-    typedef Loader<AADDR, BM, BK, VEC> LA;
-    typedef Loader<BADDR, BN, BK, VEC> LB;
+    typedef Loader<AADDR, BM, BK, VEC, MF == 1> LA;
+    typedef Loader<BADDR, BN, BK, VEC, MF == 1> LB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // three LDS stages, stage s = [A tile | B tile]: during K step t the consumers read stage t % 3 (and,
     // near its end, prefetch the first fragments of stage (t+1) % 3, complete since the previous barrier)
@@ -698,9 +733,17 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
                 lb.template fetch<TAB>(rb, pb, cg, g, b, kbeg + u * d.kStep, kend, j0c, jlim, tid, ktab, bcols);
             }
         };
+        constexpr bool PSA = has_sum<AADDR>::value, PSB = has_sum<BADDR>::value;
+        float psa[PSA ? LA::NCH : 1], psb[PSB ? LB::NCH : 1];   // k-sum partials (launches that ask for sums have one tile per workgroup)
+#pragma unroll
+        for (int it = 0; it < (PSA ? LA::NCH : 1); ++it) psa[it] = 0.f;
+#pragma unroll
+        for (int it = 0; it < (PSB ? LB::NCH : 1); ++it) psb[it] = 0.f;
         auto commit = [&](const auto& la, const auto& lb, int stage) {
             la.commit(smem + stage * STAGE, tid);
             lb.commit(smem + stage * STAGE + LA::LDS_FLOATS, tid);
+            if constexpr (PSA) la.add_sums(psa);
+            if constexpr (PSB) lb.add_sums(psb);
         };
 #pragma unroll
         for (int u = 0; u < NS; ++u)
@@ -761,6 +804,12 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
                 }
             }
         }
+        if constexpr (PSA) {
+            if (ep.sumOut && blockIdx.x == 0) LA::sum_rows(psa, ep.sumOut + q * ep.sumStride + g * ep.rowG, ep.sumAlpha, i0, ilim, tid);
+        }
+        if constexpr (PSB) {
+            if (ep.sumOut && blockIdx.y == 0) LB::sum_rows(psb, ep.sumOut + q * ep.sumStride + g * ep.colG, ep.sumAlpha, j0c, jlim, tid);
+        }
         };
         const bool onePerTile = (int)gridDim.x == d.colTiles;
         if constexpr (has_ktab<BADDR>::value) {
@@ -779,128 +828,76 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         // ------------------------------ consumer waves, 16x16x4 blocks ------------------------------
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int lq = lane >> 4, l15 = lane & 15, par = lq & 1;   // lq: lane group (q is this workgroup's K chunk)
-        const bool hi = lane >= 32;
+        const int lq = lane >> 4, l15 = lane & 15;   // lq: lane group (q is this workgroup's K chunk)
         const int wm = wave / WN, wn = wave % WN;
         f32x4 acc[MT][NT];
-        constexpr bool SUMA = has_sum<AADDR>::value, SUMB = has_sum<BADDR>::value;
-        float rs[MT], cs[NT];
-        (void)rs; (void)cs;
-        // A K step is BK / 8 groups of 8 k's = two 16-byte chunks per row in the KC layout; lane group lq reads chunk (lq & 1) of
-        // the group whole and feeds element (lq >> 1) + 2 m of it to MFMA m.  Two fragment sets: group g + 1 (or group 0 of the next
-        // stage, complete since the previous barrier) is requested before the MFMAs of group g.
+        // A K step is BK / 8 groups of 8 k's = two 16-byte chunks per row.  MFMA m (0, 1) of a group takes from lane group lq
+        // k = 4 (lq & 1) + 2 m + (lq >> 1) -- over the four lane groups k = 0,4,1,5 then 2,6,3,7, the order of the 32x32x2 path --
+        // and the permuted chunk layout (Loader, PERM) puts a lane's two values side by side: ONE ds_read_b64 per 16-row block and
+        // group, no other vector instruction in the loop.  That matters: a wave's vector and LDS instructions do NOT run in the
+        // shadow of its own matrix instructions (tools/census/mfma16_probe.hip), and there is one consumer wave per SIMD.
+        // Two fragment sets: group g + 1 (or group 0 of the next stage, complete since the previous barrier) is requested before
+        // the MFMAs of group g.
         constexpr int GROUPS = BK / 8;
-        float4 fa[MT], fb[NT];   // ONE fragment set: a group's MFMA operands are copied out of it, then it is refilled under the MFMAs
-        auto load_group = [&](const float* cA, const float* cB, int g_) {
+        static_assert(GROUPS % 2 == 0, "fragment sets alternate by group parity across K steps");
+        const int half = (lq >> 1) ^ (lq & 1), par = lq & 1;
+        float2 fa[2][MT], fb[2][NT];
+        auto load_group = [&](const float* cA, const float* cB, int g_, int set) {
 #pragma unroll
-            for (int a = 0; a < MT; ++a) fa[a] = reinterpret_cast<const float4*>(cA)[(2 * g_ + par) * LA::ROWSP + (wm * MT + a) * 16 + l15];
+            for (int a = 0; a < MT; ++a) fa[set][a] = reinterpret_cast<const float2*>(cA)[((2 * g_ + par) * LA::ROWSP + (wm * MT + a) * 16 + l15) * 2 + half];
 #pragma unroll
-            for (int b = 0; b < NT; ++b) fb[b] = reinterpret_cast<const float4*>(cB)[(2 * g_ + par) * LB::ROWSP + (wn * NT + b) * 16 + l15];
+            for (int b = 0; b < NT; ++b) fb[set][b] = reinterpret_cast<const float2*>(cB)[((2 * g_ + par) * LB::ROWSP + (wn * NT + b) * 16 + l15) * 2 + half];
         };
         const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(ep.C + q * ep.chunkStride, 0, ep.cBytes, 0x00020000);
         lds_done_barrier();   // tiles 0 and 1 visible
-        load_group(smem, smem + LA::LDS_FLOATS, 0);
-        float a0[MT], b0[NT], a1[MT], b1[NT];   // operands of a group's first / second matrix instruction
-#pragma unroll
-        for (int a = 0; a < MT; ++a) a0[a] = hi ? fa[a].y : fa[a].x;
-#pragma unroll
-        for (int b = 0; b < NT; ++b) b0[b] = hi ? fb[b].y : fb[b].x;
+        load_group(smem, smem + LA::LDS_FLOATS, 0, 0);
         int stage = 0;
+        unsigned long long c0 = 0, c1 = 0, c2 = 0, cStart = 0, accM = 0, accW = 0, s0 = 0, s1 = 0, accS = 0;
+        (void)c0; (void)c1; (void)c2; (void)cStart; (void)accM; (void)accW; (void)s0; (void)s1; (void)accS;
+        STAMP(cStart);
+#ifdef MC_STAMP
+        const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
         for (int ct = blockIdx.x; ct < d.colTiles; ct += gridDim.x) {
 #pragma unroll
             for (int a = 0; a < MT; ++a)
 #pragma unroll
                 for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (SUMA) {
-#pragma unroll
-                for (int a = 0; a < MT; ++a) rs[a] = 0.f;
-            }
-            if constexpr (SUMB) {
-#pragma unroll
-                for (int b = 0; b < NT; ++b) cs[b] = 0.f;
-            }
             for (int t = 0; t < nkTile; ++t) {
                 const int nstage = stage == 2 ? 0 : stage + 1;
                 const float* cA = smem + stage * STAGE;
                 const float* cB = cA + LA::LDS_FLOATS;
                 const float* nA = smem + nstage * STAGE;   // on the last K step this stage holds stale data: read, never used
                 const float* nB = nA + LA::LDS_FLOATS;
+                STAMP(c0);
 #pragma unroll
                 for (int g_ = 0; g_ < GROUPS; ++g_) {
-                    // Pass 0 (k = 0,4,1,5 of the group's 8; operands a0 / b0 were copied out while the previous pass ran) with the
-                    // copies of pass 1's operands (elements z | w) and the k-sums issued BETWEEN its matrix instructions; then the
-                    // fragment set is refilled with the next group, which lands under pass 1, whose tail copies out the next pass 0's
-                    // operands.  The matrix pipe takes an instruction every 32 cycles; a wave's vector instructions issue in the gaps
-                    // only if they sit between the MFMAs in program order (sched_group_barrier), not in a block in front of them.
-#pragma unroll
-                    for (int a = 0; a < MT; ++a)
-#pragma unroll
-                        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[a], b0[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-                    for (int a = 0; a < MT; ++a) a1[a] = hi ? fa[a].w : fa[a].z;
-#pragma unroll
-                    for (int b = 0; b < NT; ++b) b1[b] = hi ? fb[b].w : fb[b].z;
-                    // k-sums in the order of the 32x32 path: a lane adds its chunk's four k values in turn (lane groups 0 and 1 hold the
-                    // two chunks of the group, groups 2 and 3 copies), the two chunk sums are combined at the end of the tile
-                    if constexpr (SUMA) {
-#pragma unroll
-                        for (int a = 0; a < MT; ++a) { rs[a] += fa[a].x; rs[a] += fa[a].y; rs[a] += fa[a].z; rs[a] += fa[a].w; }
-                    }
-                    if constexpr (SUMB) {
-#pragma unroll
-                        for (int b = 0; b < NT; ++b) { cs[b] += fb[b].x; cs[b] += fb[b].y; cs[b] += fb[b].z; cs[b] += fb[b].w; }
-                    }
-#pragma unroll
-                    for (int i = 0; i < MT * NT; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // up to two VALU in its shadow
-                    }
+                    const int set = g_ & 1;
+                    if (g_ + 1 < GROUPS) load_group(cA, cB, g_ + 1, set ^ 1);
+                    else load_group(nA, nB, 0, set ^ 1);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (g_ + 1 < GROUPS) load_group(cA, cB, g_ + 1);
-                    else load_group(nA, nB, 0);
 #pragma unroll
                     for (int a = 0; a < MT; ++a)
 #pragma unroll
-                        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[a], b1[b], acc[a][b], 0, 0, 0);
+                        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][a].x, fb[set][b].x, acc[a][b], 0, 0, 0);
 #pragma unroll
-                    for (int a = 0; a < MT; ++a) a0[a] = hi ? fa[a].y : fa[a].x;
+                    for (int a = 0; a < MT; ++a)
 #pragma unroll
-                    for (int b = 0; b < NT; ++b) b0[b] = hi ? fb[b].y : fb[b].x;
-                    __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);   // the LDS reads first
-                    __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - (MT + NT), 0);
-#pragma unroll
-                    for (int i = 0; i < MT + NT; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                    }
+                        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][a].y, fb[set][b].y, acc[a][b], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                STAMP(c1);
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+                STAMP(c2);
+#ifdef MC_STAMP
+                accM += c1 - c0; accW += c2 - c1;
+#endif
                 stage = nstage;
             }
+            STAMP(s0);
             const int j0 = coff + col_block(ct) * BN;
-            if constexpr (SUMA) {
-                if (ep.sumOut) {
-#pragma unroll
-                    for (int a = 0; a < MT; ++a) {
-                        const float v = rs[a] + __shfl_xor(rs[a], 16);
-                        const int i = i0 + (wm * MT + a) * 16 + l15;
-                        if (ct == 0 && wn == 0 && lq == 0 && i < ilim) ep.sumOut[q * ep.sumStride + i + g * ep.rowG] = ep.sumAlpha * v;
-                    }
-                }
-            }
-            if constexpr (SUMB) {
-                if (ep.sumOut) {
-#pragma unroll
-                    for (int b = 0; b < NT; ++b) {
-                        const float v = cs[b] + __shfl_xor(cs[b], 16);
-                        const int j = j0 + (wn * NT + b) * 16 + l15;
-                        if (blockIdx.y == 0 && wm == 0 && lq == 0 && j < jlim) ep.sumOut[q * ep.sumStride + j + g * ep.colG] = ep.sumAlpha * v;
-                    }
-                }
-            }
             // store: C/D map of the 16x16 block: col = lane & 15, row = 4 * (lane >> 4) + r.  Branch-free through the chunk's descriptor.
             const unsigned ldcB = (unsigned)ep.ldc * 4u;
             const bool relu = ep.act == MC_NEURON_RELU;
@@ -930,7 +927,18 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
                     }
                 }
             }
+            STAMP(s1);
+#ifdef MC_STAMP
+            accS += s1 - s0;
+#endif
         }
+#ifdef MC_STAMP
+        if (threadIdx.x == 0) {
+            const int blk = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+            if (blk < 8192) { g_stamp[blk * 8 + 0] = c2 - cStart; g_stamp[blk * 8 + 1] = accM; g_stamp[blk * 8 + 2] = ((rt1 - rt0) << 32) | (accW & 0xFFFFFFFFull); g_stamp[blk * 8 + 3] = (unsigned long long)nk | (accS << 32); }
+        }
+#endif
         return;
     }
     // ------------------------------ consumer waves ------------------------------
@@ -941,9 +949,6 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     const int wm = w2 / WN, wn = w2 % WN;
 
     f32x16 acc[MT][NT];
-    constexpr bool SUMA = has_sum<AADDR>::value && KQ == 1, SUMB = has_sum<BADDR>::value && KQ == 1;
-    float rs[MT], cs[NT];   // SUMA / SUMB: this lane's share of the k-sums of its A rows / B columns
-    (void)rs; (void)cs;
 
     // LDS -> register fragments, software-pipelined ACROSS K steps: "slab" s holds the operands of one
     // MFMA k-step (2 k values: lane half h supplies k = kof(s) + h-dependent offset).  The reads of slab
@@ -1126,14 +1131,6 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         for (int b = 0; b < NT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    if constexpr (SUMA) {
-#pragma unroll
-        for (int a = 0; a < MT; ++a) rs[a] = 0.f;
-    }
-    if constexpr (SUMB) {
-#pragma unroll
-        for (int b = 0; b < NT; ++b) cs[b] = 0.f;
-    }
     for (int t = 0; t < nkTile; ++t) {
         const int nstage = stage == 2 ? 0 : stage + 1;
         STAMP(c0);
@@ -1151,14 +1148,6 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s_][a], bf[s_][b], acc[a][b], 0, 0, 0);
-            if constexpr (SUMA) {   // a handful of adds under MT * NT matrix instructions of 64 cycles each
-#pragma unroll
-                for (int a = 0; a < MT; ++a) rs[a] += af[s_][a];
-            }
-            if constexpr (SUMB) {
-#pragma unroll
-                for (int b = 0; b < NT; ++b) cs[b] += bf[s_][b];
-            }
             __builtin_amdgcn_sched_barrier(0);
         }
         // end of K step t.  No LDS wait here: every read of this stage has been consumed by an MFMA above,
@@ -1198,27 +1187,6 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
                 for (int r = 0; r < 16; ++r) acc[a][b][r] += red[((a * NT + b) * 16 + r) * 64 + lane];
             }
         __builtin_amdgcn_sched_barrier(0);
-    }
-    // k-sums: the two lane halves hold alternate groups of four k values; waves that share the operand hold copies
-    if constexpr (SUMA) {
-        if (ep.sumOut) {
-#pragma unroll
-            for (int a = 0; a < MT; ++a) {
-                const float v = rs[a] + __shfl_xor(rs[a], 32);
-                const int i = i0 + (wm * MT + a) * 32 + l31;
-                if (ct == 0 && wn == 0 && h == 0 && i < ilim) ep.sumOut[q * ep.sumStride + i + g * ep.rowG] = ep.sumAlpha * v;
-            }
-        }
-    }
-    if constexpr (SUMB) {
-        if (ep.sumOut) {
-#pragma unroll
-            for (int b = 0; b < NT; ++b) {
-                const float v = cs[b] + __shfl_xor(cs[b], 32);
-                const int j = coff + col_block(ct) * BN + (wn * NT + b) * 32 + l31;
-                if (blockIdx.y == 0 && wm == 0 && h == 0 && j < jlim) ep.sumOut[q * ep.sumStride + j + g * ep.colG] = ep.sumAlpha * v;
-            }
-        }
     }
     // this tile's K loop is complete: store it while the producers run ahead into the next tile
     STAMP(s0);
@@ -1278,7 +1246,8 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
     // running its tiles as one pipeline (see the kernel) instead of paying the pipeline fill per tile.
     const int stepsPerTile = ceil_div(d.kChunk < d.Kg ? d.kChunk : d.Kg, BK);
     static const bool nopersist = getenv("MC_IGEMM_NOPERSIST") != nullptr;
-    if (KQ == 1 && !nopersist && stepsPerTile <= 24 && (long)grid.x * grid.y * grid.z > 2L * num_cus()) {
+    // (not when k-sums are asked for: the producers form them per workgroup, which then has exactly one tile)
+    if (KQ == 1 && !nopersist && !ep.sumOut && stepsPerTile <= 24 && (long)grid.x * grid.y * grid.z > 2L * num_cus()) {
         // resident workgroups per CU at this LDS footprint (it varies with the k table): cached as (lds << 8 | count)
         const int cached = perCU[dev].load(std::memory_order_relaxed);
         int pc = (cached >> 8) == (int)(lds >> 8) ? (cached & 0xFF) : 0;
@@ -1339,10 +1308,11 @@ int launch_tile(int tile, const typename AADDR::P& pa, const typename BADDR::P& 
     if constexpr (!tile_fits<AADDR, BADDR, 3, 2, 2, 2, BK, VEC>()) tile = tile == T32 ? T21 : tile;
     if constexpr (mf_ok<AADDR, BADDR, BK, EPI>()) {
         switch (tile) {
+// (the two largest tiles keep two producer register sets instead of three: with three the producers spill inside their K loop)
 #define MC_MF_CASE(T, MT_, NT_)                                                                                                       \
             case T:                                                                                                                   \
                 if constexpr (tile_fits<AADDR, BADDR, MT_, NT_, 2, 2, BK, VEC, 16>())                                                 \
-                    return launch_cfg<AADDR, BADDR, MT_, NT_, 2, 2, BK, VEC, EPI, MC_NS, 1, 1>(pa, pb, cg, d, ep, chunks, st);            \
+                    return launch_cfg<AADDR, BADDR, MT_, NT_, 2, 2, BK, VEC, EPI, (MT_ * NT_ >= 30 ? 2 : MC_NS), 1, 1>(pa, pb, cg, d, ep, chunks, st); \
                 break;
             MC_MF_CASE(M56, 5, 6)
             MC_MF_CASE(M35, 3, 5)

@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libmckernels.so")
+_LIB_PATH = os.environ.get("MC_KERNELS_LIB") or os.path.join(_HERE, "libmckernels.so")   # the override: tuning variants (tools/build_variant.sh)
 
 c_fp = ctypes.c_void_p
 c_i = ctypes.c_int

@@ -96,7 +96,8 @@ def test_noalloc_entry_first_on_a_fresh_shape_under_stream_capture():
     m.call("mc_conv_weight_grad_noalloc", ptr(dimg), ptr(dhid), ptr(got), *geo, 0.0, 1.0, handle)
     assert hip.hipStreamSynchronize(handle) == 0
     assert hip.hipMemGetInfo(ctypes.byref(free1), ctypes.byref(tot)) == 0
-    assert free1.value == free0.value, "the entry point changed the device's free memory"
+    # (>=: the runtime may hand back what the destroyed graph held; what must not happen is that less is free)
+    assert free1.value >= free0.value, "the entry point took device memory"
     m.call("mc_conv_weight_grad", ptr(dimg), ptr(dhid), ptr(ref), *geo, 0.0, 1.0, ptr(ws), wsb, None)
     assert np.array_equal(host(got), host(ref))
     assert relerr(host(got), G.weight_acts(img, hid, *geo, partial_sum=0)) < TOL
