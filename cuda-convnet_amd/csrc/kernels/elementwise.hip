@@ -3,6 +3,7 @@
 // All are coalesced over the innermost (image) axis, 16 bytes per lane where alignment allows,
 // grid-stride with at most 8 workgroups per CU.
 #include "mc_common.h"
+#include "philox.h"
 
 namespace mc {
 namespace {
@@ -124,18 +125,7 @@ struct GLinear { float a; __device__ float operator()(float g, float) const { re
 // dropout: PluginsSrc/include/extralayers.cuh:81-96
 struct FDropout { float p; __device__ float operator()(float src, float u) const { return u < p ? 0.f : src; } };
 
-// ---------------------------------------------------------------- Philox4x32-10
-__device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned k0, unsigned k1) {
-    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
-    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
-    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
-    const unsigned n1 = (unsigned)p1;
-    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
-    const unsigned n3 = (unsigned)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-}
-__device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }  // [0,1)
-
+// ---------------------------------------------------------------- Philox4x32-10 (philox.h)
 __global__ void k_rand_uniform(float* out, size_t n, unsigned long long seed, unsigned long long offset) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t nblk = (n + 3) / 4;

@@ -5,6 +5,7 @@
 // (kLocalMaxUndo :1502, kLocalAvgUndo :1395, kCNorm_manyfilter :831, kRNormUndoPrelims :1603,
 // kRNormUndo :1639, kFCNorm :1041, kFRNormUndo :1115).
 #include "mc_common.h"
+#include "philox.h"
 
 namespace mc {
 namespace {
@@ -60,6 +61,27 @@ __device__ __forceinline__ float vpow(float a, float e) { return fast_pow(a, e);
 template <class T>
 __device__ __forceinline__ T blend(T old, T v, float sT, float sO) { return vadd(vscale(old, sT), vscale(v, sO)); }
 
+// Dropout in the pool's store (DROP): the pooled value goes to `target` as always (the max-undo routes by it), and
+// (u < p ? 0 : value) -- u the counter-based uniform of the element, block (flat index / 4) of stream (seed, offset), exactly
+// what mc_dropout_counter draws for it -- goes to dp.out; dp.keep gets one byte per four elements, bit e = (u_e >= p), which
+// the backward pass reads instead of running Philox again for every window that overlaps a pixel block.
+struct DropArgs {
+    float* out;
+    unsigned char* keep;
+    float p;
+    unsigned long long seed, offset;
+};
+__device__ __forceinline__ float4 drop4(float4 v, const DropArgs& dp, size_t flat, unsigned& bits) {
+    float u[4];
+    philox_uniform4(dp.seed, dp.offset, flat >> 2, u);
+    bits = (u[0] < dp.p ? 0u : 1u) | (u[1] < dp.p ? 0u : 2u) | (u[2] < dp.p ? 0u : 4u) | (u[3] < dp.p ? 0u : 8u);
+    return make_float4(u[0] < dp.p ? 0.f : v.x, u[1] < dp.p ? 0.f : v.y, u[2] < dp.p ? 0.f : v.z, u[3] < dp.p ? 0.f : v.w);
+}
+// gradient of four elements behind a dropout whose keep bits are `bits`
+__device__ __forceinline__ float4 keep4(float4 g, unsigned bits) {
+    return make_float4((bits & 1u) ? g.x : 0.f, (bits & 2u) ? g.y : 0.f, (bits & 4u) ? g.z : 0.f, (bits & 8u) ? g.w : 0.f);
+}
+
 // item -> (row = channel*pixels + px, image chunk)
 template <int V>
 __device__ __forceinline__ bool decode(size_t item, int nChunks, int& row, int& n) {
@@ -102,10 +124,13 @@ __device__ __forceinline__ void out_range(int p, int start, int subs, int stride
 }
 
 // ------------------------------------------------------------------ max-pool undo
+// the gradient of element(s) o behind a fused dropout: zero where the keep bit is clear (keep == nullptr: no dropout)
+__device__ __forceinline__ float4 kept(float4 g, const unsigned char* keep, size_t o) { return keep ? keep4(g, keep[o >> 2]) : g; }
+__device__ __forceinline__ float kept(float g, const unsigned char* keep, size_t o) { return (!keep || ((keep[o >> 2] >> (o & 3)) & 1)) ? g : 0.f; }
 template <int V, bool RELU>
 __global__ void k_max_undo(const float* __restrict__ imgs, const float* __restrict__ maxGrads,
                            const float* __restrict__ maxActs, float* target, int N, int C, int imgSize, int subsX,
-                           int startX, int strideX, int outputsX, float sT, float sO) {
+                           int startX, int strideX, int outputsX, float sT, float sO, const unsigned char* __restrict__ keep) {
     typedef Vec<V> VV;
     const int nChunks = N / V;
     const int imgPix = imgSize * imgSize, numOut = outputsX * outputsX;
@@ -125,7 +150,7 @@ __global__ void k_max_undo(const float* __restrict__ imgs, const float* __restri
             for (int my = ylo; my < yhi; ++my)
                 for (int mx = xlo; mx < xhi; ++mx) {
                     const size_t o = ((size_t)c * numOut + my * outputsX + mx) * N + n;
-                    prod = vadd(prod, veqmul(img, VV::ld(maxActs + o), VV::ld(maxGrads + o)));
+                    prod = vadd(prod, veqmul(img, VV::ld(maxActs + o), kept(VV::ld(maxGrads + o), keep, o)));
                 }
             if (RELU) prod = vposmask(img, prod);   // the pooled images are a relu's output: its gradient mask, fused
         }
@@ -179,9 +204,9 @@ __global__ void __launch_bounds__(256) k_pool_2d(const float* __restrict__ imgs,
 // k_pool_2d for a compile-time window (2x2, 3x3: every shipped strided pool): the window loop is unrolled and branch-free, so
 // all SIZE^2 loads are in flight together.  A tap outside the image re-reads the nearest tap inside (max: a duplicate changes
 // nothing) or enters the sum as +0 (avg: same order of the in-image terms as the loops of k_pool_2d).
-template <bool MAX, int SIZE>
+template <bool MAX, int SIZE, bool DROP = false>
 __global__ void __launch_bounds__(256) k_pool_fix(const float* __restrict__ imgs, float* __restrict__ target, int N, int imgSize,
-                                                  int startX, int strideX, int outputsX, Map2D mp) {
+                                                  int startX, int strideX, int outputsX, Map2D mp, DropArgs dp = DropArgs{}) {
     typedef Vec<4> VV;
     const int LX = 1 << mp.lxShift;
     const int nl = threadIdx.x & (LX - 1), oxl = threadIdx.x >> mp.lxShift;
@@ -194,7 +219,6 @@ __global__ void __launch_bounds__(256) k_pool_fix(const float* __restrict__ imgs
     const int numOut = outputsX * outputsX;
     const int oyEnd = min(outputsX, (yb + 1) * mp.band);
     const float* src = imgs + (size_t)c * imgSize * imgSize * N;
-    float* dst = target + (size_t)c * numOut * N;
     for (int n = nl * 4; n < N; n += LX * 4)
         for (int oy = yb * mp.band; oy < oyEnd; ++oy) {
             const int sy = startX + oy * strideX;
@@ -219,14 +243,40 @@ __global__ void __launch_bounds__(256) k_pool_fix(const float* __restrict__ imgs
                     }
                 }
             if (!MAX) acc = vdivs(acc, (float)((y1 - y0) * (x1 - x0)));
-            VV::st(dst + (size_t)(oy * outputsX + ox) * N + n, acc);
+            const size_t flat = (size_t)c * numOut * N + (size_t)(oy * outputsX + ox) * N + n;
+            VV::st(target + flat, acc);
+            if constexpr (DROP) {
+                unsigned bits;
+                VV::st(dp.out + flat, drop4(acc, dp, flat, bits));
+                dp.keep[flat >> 2] = (unsigned char)bits;
+            }
         }
+}
+
+// the general form of the fused forward pass: dropout of an already pooled tensor, with the keep bytes (any n, any alignment)
+__global__ void k_dropout_keep(const float* __restrict__ in, float* out, unsigned char* keep, size_t n, float p, unsigned long long seed,
+                               unsigned long long offset) {
+    const size_t nblk = (n + 3) / 4;
+    for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += (size_t)gridDim.x * blockDim.x) {
+        float u[4];
+        philox_uniform4(seed, offset, b, u);
+        unsigned bits = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (b * 4 + e < n) {
+                const bool kp = !(u[e] < p);
+                bits |= kp ? (1u << e) : 0u;
+                out[b * 4 + e] = kp ? in[b * 4 + e] : 0.f;
+            }
+        keep[b] = (unsigned char)bits;
+    }
 }
 
 template <bool RELU>
 __global__ void __launch_bounds__(256) k_max_undo_2d(const float* __restrict__ imgs, const float* __restrict__ maxGrads,
                                                      const float* __restrict__ maxActs, float* target, int N, int imgSize, int subsX,
-                                                     int startX, int strideX, int outputsX, float sT, float sO, Map2D mp) {
+                                                     int startX, int strideX, int outputsX, float sT, float sO, Map2D mp,
+                                                     const unsigned char* __restrict__ keep) {
     typedef Vec<4> VV;
     const int LX = 1 << mp.lxShift;
     const int nl = threadIdx.x & (LX - 1), xl = threadIdx.x >> mp.lxShift;
@@ -252,7 +302,7 @@ __global__ void __launch_bounds__(256) k_max_undo_2d(const float* __restrict__ i
                 for (int my = ylo; my < yhi; ++my)
                     for (int mx = xlo; mx < xhi; ++mx) {
                         const size_t o = obase + (size_t)(my * outputsX + mx) * N + n;
-                        prod = vadd(prod, veqmul(img, VV::ld(maxActs + o), VV::ld(maxGrads + o)));
+                        prod = vadd(prod, veqmul(img, VV::ld(maxActs + o), kept(VV::ld(maxGrads + o), keep, o)));
                     }
                 if (RELU) prod = vposmask(img, prod);
             }
@@ -267,7 +317,8 @@ __global__ void __launch_bounds__(256) k_max_undo_2d(const float* __restrict__ i
 template <bool RELU>
 __global__ void __launch_bounds__(256) k_max_undo_s2(const float* __restrict__ imgs, const float* __restrict__ maxGrads,
                                                      const float* __restrict__ maxActs, float* target, int N, int imgSize, int subsX,
-                                                     int startX, int outputsX, float sT, float sO, Map2D mp) {
+                                                     int startX, int outputsX, float sT, float sO, Map2D mp,
+                                                     const unsigned char* __restrict__ keep) {
     typedef Vec<4> VV;
     const int LX = 1 << mp.lxShift;
     const int nl = threadIdx.x & (LX - 1), xl = threadIdx.x >> mp.lxShift;
@@ -311,7 +362,7 @@ __global__ void __launch_bounds__(256) k_max_undo_s2(const float* __restrict__ i
                     const bool ok = ky < ny && kx < nx;
                     const size_t o = obase + (ok ? (size_t)((ylo + ky) * outputsX + xlo + kx) * N : (size_t)0) + n;
                     a[ky][kx] = VV::ld(maxActs + o);
-                    g[ky][kx] = VV::ld(maxGrads + o);
+                    g[ky][kx] = kept(VV::ld(maxGrads + o), keep, o);
                     if (!ok) g[ky][kx] = z;
                 }
 #pragma unroll
@@ -722,7 +773,7 @@ int mc_conv_local_pool(const float* images, float* target, int numImages, int nu
 
 static int max_undo_entry(const char* who, bool relu, const float* images, const float* maxGrads, const float* maxActs, float* target,
                           int numImages, int numFilters, int imgSize, int subsX, int startX, int strideX, int outputsX,
-                          float scaleTargets, float scaleOutput, mcStream_t s) {
+                          float scaleTargets, float scaleOutput, mcStream_t s, const unsigned char* keep = nullptr) {
     MC_REQUIRE(images && maxGrads && maxActs && target, "%s: null pointer", who);
     MC_REQUIRE(numImages > 0 && numFilters > 0 && imgSize > 0 && subsX > 0 && strideX > 0 && outputsX > 0, "%s: non-positive dimension", who);
     MC_REQUIRE((size_t)numFilters * imgSize * imgSize * numImages < (1ull << 31), "%s: tensor exceeds 32-bit indexing", who);
@@ -734,20 +785,20 @@ static int max_undo_entry(const char* who, bool relu, const float* images, const
     if (v && numFilters <= 65535 && strideX == 2 && s2fits && !nos2) {
         dim3 g2;
         const Map2D mp = make_map2d(numImages, (imgSize + 1) / 2, (imgSize + 1) / 2, numFilters, g2);
-        if (relu) hipLaunchKernelGGL(k_max_undo_s2<true>, g2, dim3(256), 0, S(s), images, maxGrads, maxActs, target, numImages, imgSize, subsX, startX, outputsX, scaleTargets, scaleOutput, mp);
-        else hipLaunchKernelGGL(k_max_undo_s2<false>, g2, dim3(256), 0, S(s), images, maxGrads, maxActs, target, numImages, imgSize, subsX, startX, outputsX, scaleTargets, scaleOutput, mp);
+        if (relu) hipLaunchKernelGGL(k_max_undo_s2<true>, g2, dim3(256), 0, S(s), images, maxGrads, maxActs, target, numImages, imgSize, subsX, startX, outputsX, scaleTargets, scaleOutput, mp, keep);
+        else hipLaunchKernelGGL(k_max_undo_s2<false>, g2, dim3(256), 0, S(s), images, maxGrads, maxActs, target, numImages, imgSize, subsX, startX, outputsX, scaleTargets, scaleOutput, mp, keep);
         return launch_status(who);
     }
     if (v && numFilters <= 65535) {
         dim3 g2;
         const Map2D mp = make_map2d(numImages, imgSize, imgSize, numFilters, g2);
-        if (relu) hipLaunchKernelGGL(k_max_undo_2d<true>, g2, dim3(256), 0, S(s), images, maxGrads, maxActs, target, numImages, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput, mp);
-        else hipLaunchKernelGGL(k_max_undo_2d<false>, g2, dim3(256), 0, S(s), images, maxGrads, maxActs, target, numImages, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput, mp);
+        if (relu) hipLaunchKernelGGL(k_max_undo_2d<true>, g2, dim3(256), 0, S(s), images, maxGrads, maxActs, target, numImages, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput, mp, keep);
+        else hipLaunchKernelGGL(k_max_undo_2d<false>, g2, dim3(256), 0, S(s), images, maxGrads, maxActs, target, numImages, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput, mp, keep);
         return launch_status(who);
     }
     const size_t items = (size_t)numFilters * imgSize * imgSize * (numImages / (v ? 4 : 1));
     dim3 g(grid_items(items)), b(TPB);
-#define MC_MU(V, R) hipLaunchKernelGGL((k_max_undo<V, R>), g, b, 0, S(s), images, maxGrads, maxActs, target, numImages, numFilters, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput)
+#define MC_MU(V, R) hipLaunchKernelGGL((k_max_undo<V, R>), g, b, 0, S(s), images, maxGrads, maxActs, target, numImages, numFilters, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput, keep)
     if (v && relu) MC_MU(4, true);
     else if (v) MC_MU(4, false);
     else if (relu) MC_MU(1, true);
@@ -768,6 +819,43 @@ int mc_conv_local_max_undo_relu_grad(const float* images, const float* maxGrads,
                                      int outputsX, float scaleTargets, float scaleOutput, mcStream_t s) {
     return max_undo_entry("mc_conv_local_max_undo_relu_grad", true, images, maxGrads, maxActs, target, numImages, numFilters, imgSize,
                           subsX, startX, strideX, outputsX, scaleTargets, scaleOutput, s);
+}
+
+int mc_conv_local_max_undo_dropout(const float* images, const float* maxGrads, const float* maxActs, const unsigned char* keep, float* target,
+                                   int numImages, int numFilters, int imgSize, int subsX, int startX, int strideX, int outputsX,
+                                   float scaleTargets, float scaleOutput, int reluGrad, mcStream_t s) {
+    MC_REQUIRE(keep, "mc_conv_local_max_undo_dropout: null keep bytes");
+    return max_undo_entry("mc_conv_local_max_undo_dropout", reluGrad != 0, images, maxGrads, maxActs, target, numImages, numFilters, imgSize,
+                          subsX, startX, strideX, outputsX, scaleTargets, scaleOutput, s, keep);
+}
+
+size_t mc_dropout_keep_bytes(size_t n) { return (n + 3) / 4; }
+
+int mc_conv_local_pool_dropout(const float* images, float* target, float* dropTarget, unsigned char* keep, int numImages, int numFilters,
+                               int imgSize, int subsX, int startX, int strideX, int outputsX, int pooler, float prob,
+                               unsigned long long seed, unsigned long long offset, mcStream_t s) {
+    MC_REQUIRE(images && target && dropTarget && keep, "mc_conv_local_pool_dropout: null pointer");
+    MC_POOLARGS_OK("mc_conv_local_pool_dropout");
+    MC_REQUIRE(pooler == MC_POOL_MAX || pooler == MC_POOL_AVG, "mc_conv_local_pool_dropout: unknown pooler %d", pooler);
+    MC_REQUIRE(prob > 0.f && prob < 1.f, "mc_conv_local_pool_dropout: prob must be in (0,1), got %g", (double)prob);
+    MC_REQUIRE(offset % 4 == 0, "mc_conv_local_pool_dropout: offset must be a multiple of 4");
+    MC_REQUIRE(dropTarget != target, "mc_conv_local_pool_dropout: the pooled and the dropped-out tensor must be two buffers (the max-undo routes by the pooled one)");
+    const size_t n = (size_t)numFilters * outputsX * outputsX * numImages;
+    static const bool nofuse = getenv("MC_POOL_DROPOUT_TWO_PASS") != nullptr;
+    if (!nofuse && use_vec(numImages, {images, target, dropTarget}) && numFilters <= 65535 && (subsX == 2 || subsX == 3)) {
+        dim3 g2;
+        const Map2D mp = make_map2d(numImages, outputsX, outputsX, numFilters, g2);
+        const DropArgs dp{dropTarget, keep, prob, seed, offset};
+#define MC_PFD(MAXP, SZ) hipLaunchKernelGGL((k_pool_fix<MAXP, SZ, true>), g2, dim3(256), 0, S(s), images, target, numImages, imgSize, startX, strideX, outputsX, mp, dp)
+        if (pooler == MC_POOL_MAX) { if (subsX == 2) MC_PFD(true, 2); else MC_PFD(true, 3); }
+        else { if (subsX == 2) MC_PFD(false, 2); else MC_PFD(false, 3); }
+#undef MC_PFD
+        return launch_status("mc_conv_local_pool_dropout");
+    }
+    const int rc = mc_conv_local_pool(images, target, numImages, numFilters, imgSize, subsX, startX, strideX, outputsX, pooler, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_dropout_keep, dim3(grid_items((n + 3) / 4)), dim3(TPB), 0, S(s), target, dropTarget, keep, n, prob, seed, offset);
+    return launch_status("mc_conv_local_pool_dropout");
 }
 
 static int avg_undo_entry(const char* who, const float* avgGrads, const float* reluActs, float* target, int numImages, int numFilters, int imgSize,

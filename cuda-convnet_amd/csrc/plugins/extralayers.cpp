@@ -123,6 +123,7 @@ public:
 
     void activate(DevMat& inputs, DevMat& outputs, PASS_TYPE passType) override {
         _activated = true;
+        _fusedNow = false;
         _inputs = &inputs;
         _outputs = &outputs;
         if (&inputs != &outputs) outputs.resize(inputs);
@@ -142,6 +143,20 @@ public:
         }
     }
 
+    // the pool layer below applies this neuron in its own store (Neuron::beginFusedDropout): reserve the stream positions
+    // activate() would have taken, in the same place of the pass, so that fused and separate runs draw the same masks
+    bool beginFusedDropout(size_t numel, PASS_TYPE passType, float* prob, unsigned long long* seed, unsigned long long* offset) override {
+        _fusedNow = false;
+        if (passType != PASS_TRAIN) return false;
+        if (!reserveUniform(numel, &_seed, &_offset)) return false;   // an injected mask is waiting: the stored-mask path takes it
+        _activated = true;
+        _counter = true;
+        _fusedNow = true;
+        *prob = _prob; *seed = _seed; *offset = _offset;
+        return true;
+    }
+    bool fusedDropoutActive() const override { return _fusedNow; }
+
     void computeInputGrad(DevMat& actsGrad, DevMat& target, bool add, PASS_TYPE passType) override {
         if (!add && &target != &actsGrad) target.resize(actsGrad);
         if (passType == PASS_TRAIN && _counter) {
@@ -158,7 +173,7 @@ public:
 private:
     DevMat _mask;
     float _prob;
-    bool _counter = false;
+    bool _counter = false, _fusedNow = false;
     unsigned long long _seed = 0, _offset = 0;
 };
 

@@ -204,7 +204,24 @@ NeuronLayer::NeuronLayer(ConvNet* convNet, PyObject* paramsDict) : Layer(convNet
 
 void NeuronLayer::fpropActs(int, float, PASS_TYPE passType) {
     if (_fused) return;   // the producing contraction already applied relu in its epilogue, in place
+    if (_dropFwd) {       // the pool layer below wrote this layer's output in its own store (fuseDropoutIntoPool)
+        _dropFwd = false;
+        return;
+    }
     _neuron->activate(*_inputs[0], getActs(), passType);
+}
+
+bool NeuronLayer::fuseDropoutIntoPool(size_t numel, PASS_TYPE passType, float* prob, unsigned long long* seed, unsigned long long* offset) {
+    static const bool off = getenv("MC_NO_FUSE_DROPOUT") != nullptr;
+    _dropFwd = _dropBwd = false;
+    // its own output matrix (the pool's output stays the un-dropped tensor the max-undo routes by), one input
+    if (off || passType != PASS_TRAIN || _actsTarget >= 0 || _prev.size() != 1) return false;
+    if (!_neuron->beginFusedDropout(numel, passType, prob, seed, offset)) return false;
+    _dropFwd = true;
+    // backward: only when this layer hands the gradient down in place (the pool then reads the very matrix the layer above
+    // wrote) and has a single gradient producer (nothing accumulates into it)
+    _dropBwd = _actsGradTarget == 0 && _numGradProducersNext == 1;
+    return true;
 }
 
 bool NeuronLayer::canFuseGradMask() {
@@ -239,6 +256,8 @@ const unsigned* Layer::claimReluGradBits(int inpIdx) {
 }
 
 void NeuronLayer::bpropActs(DevMat& v, int, float scaleTargets, PASS_TYPE passType) {
+    if (_dropBwd && _neuron->fusedDropoutActive() && passType == PASS_TRAIN && scaleTargets == 0.f) return;   // the pool's max-undo applies the keep bytes
+    _dropBwd = false;
     if (_gradMasked) {   // the layer above stored grad * (act > 0) straight into the shared gradient matrix
         _gradMasked = false;
         return;
@@ -932,12 +951,33 @@ void AvgPoolLayer::bpropActs(DevMat& v, int, float scaleTargets, PASS_TYPE) {
         RT_MC(mc_conv_local_avg_undo(v.data(), _prev[0]->getActsGrad().data(), numCases(), _channels, _imgSize, _sizeX, _start, _stride, _outputsX, scaleTargets, 1.f, ST()));
 }
 
-void MaxPoolLayer::fpropActs(int, float, PASS_TYPE) {
+void MaxPoolLayer::fpropActs(int, float, PASS_TYPE passType) {
+    // NIN's pool -> dropout pairs: the dropout neuron's forward step in this layer's store, one pass over the pooled tensor
+    // instead of two (and the keep bytes for the backward pass)
+    _dropNext = nullptr;
+    NeuronLayer* nl = _next.size() == 1 ? dynamic_cast<NeuronLayer*>(_next[0]) : nullptr;
+    float prob = 0;
+    unsigned long long seed = 0, offset = 0;
+    if (nl && nl->fuseDropoutIntoPool(getActs().numel(), passType, &prob, &seed, &offset)) {
+        nl->getActs().resize(getActs());
+        const size_t words = (mc_dropout_keep_bytes(getActs().numel()) + 3) / 4;
+        _keep.resize(1, (int)words);
+        RT_MC(mc_conv_local_pool_dropout(_inputs[0]->data(), getActs().data(), nl->getActs().data(), reinterpret_cast<unsigned char*>(_keep.data()),
+                                         numCases(), _channels, _imgSize, _sizeX, _start, _stride, _outputsX, MC_POOL_MAX, prob, seed, offset, ST()));
+        _dropNext = nl;
+        return;
+    }
     RT_MC(mc_conv_local_pool(_inputs[0]->data(), getActs().data(), numCases(), _channels, _imgSize, _sizeX, _start, _stride, _outputsX, MC_POOL_MAX, ST()));
 }
 
-void MaxPoolLayer::bpropActs(DevMat& v, int, float scaleTargets, PASS_TYPE) {
+void MaxPoolLayer::bpropActs(DevMat& v, int, float scaleTargets, PASS_TYPE passType) {
     const float* mask = scaleTargets == 0.f ? claimReluGradMask(0) : nullptr;   // == _prev[0]->getActs()
+    if (_dropNext && _dropNext->poolUndoesDropout() && passType == PASS_TRAIN) {   // v has not passed the dropout's backward step yet: masked here
+        RT_MC(mc_conv_local_max_undo_dropout(mask ? mask : _prev[0]->getActs().data(), v.data(), getActs().data(), reinterpret_cast<const unsigned char*>(_keep.data()),
+                                             _prev[0]->getActsGrad().data(), numCases(), _channels, _imgSize, _sizeX, _start, _stride, _outputsX,
+                                             mask ? 0.f : scaleTargets, 1.f, mask ? 1 : 0, ST()));
+        return;
+    }
     if (mask)
         RT_MC(mc_conv_local_max_undo_relu_grad(mask, v.data(), getActs().data(), _prev[0]->getActsGrad().data(), numCases(), _channels, _imgSize,
                                                _sizeX, _start, _stride, _outputsX, 0.f, 1.f, ST()));

@@ -41,6 +41,12 @@ public:
     virtual void computeInputGrad(DevMat& actsGrad, DevMat& target, bool add, PASS_TYPE passType);
     // The plain relu can be folded into the producing contraction's epilogue.
     virtual bool isRelu() const { return false; }
+    // A dropout-style neuron (zero where a counter-based uniform < prob, PluginsSrc/include/extralayers.cuh:39-77) that a pool layer
+    // can apply in its own store (mc_conv_local_pool_dropout) and undo in its own backward pass.  beginFusedDropout is called
+    // INSTEAD of activate() in a training pass and reserves the uniforms exactly as activate() would; false = not now (injected
+    // masks, test passes): call activate().  fusedDropoutActive: this pass's forward step went that way.
+    virtual bool beginFusedDropout(size_t numel, PASS_TYPE passType, float* prob, unsigned long long* seed, unsigned long long* offset) { return false; }
+    virtual bool fusedDropoutActive() const { return false; }
     static Neuron& makeNeuron(PyObject* neuronDict);
 
 protected:
@@ -215,12 +221,18 @@ public:
     unsigned* bitsBuffer(int rows, int ld);
     void setBitsValid(bool v) { _bitsValid = v; }
     const unsigned* validBits() const { return _bitsValid ? reinterpret_cast<const unsigned*>(_bits.data()) : nullptr; }
-    void abortPass() override { Layer::abortPass(); _gradMasked = false; _bitsValid = false; }
+    void abortPass() override { Layer::abortPass(); _gradMasked = false; _bitsValid = false; _dropFwd = _dropBwd = false; }
+    // Dropout fused into the pool layer below (MaxPoolLayer): the pool asks in its forward step; a yes means it writes this
+    // layer's output itself (this layer's own forward step is then skipped) and, when the gradient side allows it -- this layer
+    // hands its gradient down in place and nothing accumulates -- also masks the gradient in its max-undo (backward step skipped).
+    bool fuseDropoutIntoPool(size_t numel, PASS_TYPE passType, float* prob, unsigned long long* seed, unsigned long long* offset);
+    bool poolUndoesDropout() const { return _dropBwd; }
 
 protected:
     void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
     void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
     Neuron* _neuron;
+    bool _dropFwd = false, _dropBwd = false;
     bool _fused = false;
     bool _gradMasked = false;   // this pass's gradient already carries the relu mask (see claimReluGradMask)
     bool _bitsValid = false;
@@ -445,10 +457,13 @@ protected:
 class MaxPoolLayer : public PoolLayer {
 public:
     MaxPoolLayer(ConvNet* convNet, PyObject* paramsDict) : PoolLayer(convNet, paramsDict) {}
+    void abortPass() override { PoolLayer::abortPass(); _dropNext = nullptr; }
 
 protected:
     void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
     void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
+    NeuronLayer* _dropNext = nullptr;   // this pass: the dropout layer above whose forward step ran inside this layer's
+    DevMat _keep;                       // its keep bytes (one per four elements), held in a float matrix
 };
 
 class ResponseNormLayer : public Layer {

@@ -45,6 +45,8 @@ _SIGS = {
     "mc_conv_local_max_undo_relu_grad": [c_fp] * 4 + [c_i] * 7 + [c_f, c_f, c_fp],
     "mc_conv_local_pool": [c_fp, c_fp] + [c_i] * 8 + [c_fp],
     "mc_conv_local_max_undo": [c_fp] * 4 + [c_i] * 7 + [c_f, c_f, c_fp],
+    "mc_conv_local_pool_dropout": [c_fp] * 4 + [c_i] * 8 + [c_f, c_u64, c_u64, c_fp],
+    "mc_conv_local_max_undo_dropout": [c_fp] * 5 + [c_i] * 7 + [c_f, c_f, c_i, c_fp],
     "mc_conv_local_avg_undo": [c_fp] * 2 + [c_i] * 7 + [c_f, c_f, c_fp],
     "mc_conv_local_avg_undo_relu_grad": [c_fp] * 3 + [c_i] * 7 + [c_f, c_fp],
     "mc_conv_response_norm": [c_fp] * 3 + [c_i] * 4 + [c_f, c_f, c_fp],
@@ -103,7 +105,7 @@ def exported_symbols():
     """Names every build of the library must export (those include/mc_kernels.h declares)."""
     return sorted(list(_SIGS) + ["mc_last_error", "mc_gemm_workspace_bytes", "mc_conv_weight_grad_workspace_bytes",
                                    "mc_noalloc_scratch_bytes", "mc_conv_split_workspace_bytes", "mc_relu_bits_words",
-                                   "mc_conv_weight_grad_bias_workspace_bytes", "mc_gemm_row_sums_workspace_bytes"])
+                                   "mc_conv_weight_grad_bias_workspace_bytes", "mc_gemm_row_sums_workspace_bytes", "mc_dropout_keep_bytes"])
 
 
 def lib():
@@ -132,6 +134,8 @@ def lib():
         L.mc_relu_bits_words.restype = c_sz
         L.mc_conv_split_workspace_bytes.argtypes = [c_i] * 9
         L.mc_conv_split_workspace_bytes.restype = c_sz
+        L.mc_dropout_keep_bytes.argtypes = [c_sz]
+        L.mc_dropout_keep_bytes.restype = c_sz
         _lib = L
     return _lib
 

@@ -235,6 +235,24 @@ int mc_conv_local_max_undo_relu_grad(const float* images, const float* maxGrads,
                                      float* target, int numImages, int numFilters, int imgSize,
                                      int subsX, int startX, int strideX, int outputsX,
                                      float scaleTargets, float scaleOutput, mcStream_t stream);
+/* convLocalPool followed by the plugin's dropout neuron (PluginsSrc/include/extralayers.cuh:39-77, train mode: u < prob ? 0 : x,
+ * no rescale) in ONE pass over the pooled tensor: `target` gets the pooled values (convLocalMaxUndo routes by them,
+ * conv_util.cu:1567), `dropTarget` (another buffer) what mc_dropout_counter(target, dropTarget, prob, 0, n, seed, offset) would
+ * write, bit for bit, and `keep` one byte per four elements of the (features, numImages) tensor in flat order -- bit e of byte
+ * i / 4 = element 4 (i / 4) + e survived -- mc_dropout_keep_bytes(n) bytes.  NIN's pool -> dropout pairs (NIN/cifar-10_def). */
+size_t mc_dropout_keep_bytes(size_t n);
+int mc_conv_local_pool_dropout(const float* images, float* target, float* dropTarget, unsigned char* keep,
+                               int numImages, int numFilters, int imgSize, int subsX, int startX,
+                               int strideX, int outputsX, int pooler, float prob, unsigned long long seed,
+                               unsigned long long offset, mcStream_t stream);
+/* convLocalMaxUndo whose incoming gradient still has to pass the dropout neuron's backward step (extralayers.cuh:60-77,
+ * grad where the element survived, else 0): the keep bytes of mc_conv_local_pool_dropout are applied to maxGrads as they are
+ * read.  Equals mc_dropout_counter on maxGrads followed by mc_conv_local_max_undo (reluGrad = 0) or
+ * mc_conv_local_max_undo_relu_grad (reluGrad = 1), bit for bit. */
+int mc_conv_local_max_undo_dropout(const float* images, const float* maxGrads, const float* maxActs,
+                                   const unsigned char* keep, float* target, int numImages, int numFilters,
+                                   int imgSize, int subsX, int startX, int strideX, int outputsX,
+                                   float scaleTargets, float scaleOutput, int reluGrad, mcStream_t stream);
 int mc_conv_local_avg_undo(const float* avgGrads, float* target, int numImages, int numFilters,
                            int imgSize, int subsX, int startX, int strideX, int outputsX,
                            float scaleTargets, float scaleOutput, mcStream_t stream);

@@ -309,6 +309,47 @@ def test_dropout_counter_equals_stored_mask(n):
     assert abs(kept - 0.5) < 0.05
 
 
+@pytest.mark.parametrize("N,C,S,size,start,stride", [(128, 96, 32, 3, 0, 2), (128, 16, 8, 2, 1, 2), (16, 8, 9, 4, -1, 2), (6, 16, 6, 4, -2, 4),
+                                                     (5, 3, 7, 3, 0, 2), (12, 8, 9, 3, 0, 2)])
+def test_pool_with_fused_dropout(N, C, S, size, start, stride):
+    """NIN's pool -> dropout pairs as one forward and one backward pass: mc_conv_local_pool_dropout writes the pooled tensor, its
+    dropped-out copy and the keep bytes; mc_conv_local_max_undo_dropout applies the keep bytes to the gradient as it routes it.
+    Bit-identical to the separate kernels (pool, mc_dropout_counter forward, mc_dropout_counter on the gradient, max-undo with and
+    without the relu gradient) on the 3x3 / 2x2 fast paths, the general path, and cases whose images are not a multiple of 4."""
+    import torch
+    m = mc()
+    rng = np.random.default_rng(61)
+    outX = int(np.ceil((S - start - size) / float(stride))) + 1
+    x = np.maximum(rng.standard_normal((C * S * S, N)).astype(np.float32), 0)       # a relu's output: zero plateaus, ties
+    n = C * outX * outX * N
+    p, seed, off = 0.5, 987654321, 4 * 12345
+    dx = dev(x)
+    y0, d0 = nans(C * outX * outX, N), nans(C * outX * outX, N)
+    m.call("mc_conv_local_pool", ptr(dx), ptr(y0), N, C, S, size, start, stride, outX, m.POOL_MAX, None)
+    m.call("mc_dropout_counter", ptr(y0), ptr(d0), p, 0, n, seed, off, None)
+    y1, d1 = nans(C * outX * outX, N), nans(C * outX * outX, N)
+    keep = torch.full((int(m.lib().mc_dropout_keep_bytes(n)),), 255, dtype=torch.uint8, device="cuda")
+    m.call("mc_conv_local_pool_dropout", ptr(dx), ptr(y1), ptr(d1), keep.data_ptr(), N, C, S, size, start, stride, outX, m.POOL_MAX, p, seed, off, None)
+    assert np.array_equal(host(y1), host(y0)) and np.array_equal(host(d1), host(d0))
+    u = zeros(n)
+    m.call("mc_rand_uniform", ptr(u), n, seed, off, None)
+    bits = (host(u) >= p).astype(np.uint8)
+    bits = np.concatenate([bits, np.zeros((-n) % 4, np.uint8)]).reshape(-1, 4)
+    assert np.array_equal(host(keep), (bits * np.array([1, 2, 4, 8], np.uint8)).sum(axis=1).astype(np.uint8))
+    g = dev(rng.standard_normal((C * outX * outX, N)))
+    gd = nans(C * outX * outX, N)
+    m.call("mc_dropout_counter", ptr(g), ptr(gd), p, 0, n, seed, off, None)
+    prev = rng.standard_normal(x.shape).astype(np.float32)
+    for relu in (0, 1):
+        for sT in ((0.0,) if relu else (0.0, 1.0)):
+            a = nans(*x.shape) if sT == 0 else dev(prev)
+            b = nans(*x.shape) if sT == 0 else dev(prev)
+            m.call("mc_conv_local_max_undo_relu_grad" if relu else "mc_conv_local_max_undo", ptr(dx), ptr(gd), ptr(y0), ptr(a), N, C, S, size, start,
+                   stride, outX, sT, 1.0, None)
+            m.call("mc_conv_local_max_undo_dropout", ptr(dx), ptr(g), ptr(y1), keep.data_ptr(), ptr(b), N, C, S, size, start, stride, outX, sT, 1.0, relu, None)
+            assert np.array_equal(host(a), host(b)), (relu, sT)
+
+
 def test_bias_and_reductions():
     m = mc()
     rng = np.random.default_rng(20)

@@ -398,6 +398,19 @@ def test_counter_dropout_equals_stored_masks():
     assert not np.array_equal(a["W:conv2:0"], c["W:conv2:0"])        # another seed is another mask
 
 
+@pytest.mark.parametrize("net_name,cases,mini", [("nin-tiny", 128 + 70, 128), ("nin", 2 * 16 + 6, 16)])
+def test_dropout_fused_into_the_pools_changes_no_bit(net_name, cases, mini):
+    """The max-pool layers below NIN's dropout layers apply the dropout in their own store and its backward step in their own
+    max-undo (MaxPoolLayer::fpropActs / bpropActs, mc_conv_local_pool_dropout / mc_conv_local_max_undo_dropout): same uniforms
+    from the same stream positions, so everything the batch leaves behind equals a run with the separate kernels
+    (MC_NO_FUSE_DROPOUT=1) bit for bit -- full and ragged minibatches, and the forked steps from the third minibatch on."""
+    a, _ = run_child(net=net_name, cases=cases, mini=mini, philox_seed=4321)
+    b, _ = run_child(net=net_name, cases=cases, mini=mini, philox_seed=4321, _env={"MC_NO_FUSE_DROPOUT": "1"})
+    for k in a:
+        if k.startswith(("W:", "B:", "Winc:", "Binc:", "cost:")):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
 @pytest.mark.parametrize("net_name,cases,mini", [("nin-tiny", 128, 64), ("nin-tiny", 6 * 32, 32), ("conv-local", 5 * 16, 16)])
 def test_single_rank_rccl_path_is_identity(net_name, cases, mini):
     """world_size 1 through the real RCCL all-reduce / side-stream / event path gives the same
