@@ -466,7 +466,9 @@ float* ConvNet::workspace(size_t bytes) {
             }
             _branchWorkspaceBytes = (bytes + (4u << 20)) / (4u << 20) * (4u << 20);
             RT_HIP(hipMalloc(reinterpret_cast<void**>(&_branchWorkspace), _branchWorkspaceBytes));
-            DeviceAllocator::get().noteForeignAllocation();   // a graph captured with MC_STEP_FORK=graph holds the old address
+            // captured steps reference the branch workspace only when they fork too (MC_STEP_FORK=graph): then a graph of another
+            // shape holds the address just freed and must go; otherwise no graph knows this buffer
+            if (_forkGraph) DeviceAllocator::get().noteForeignAllocation();
         }
         return _branchWorkspace;
     }
