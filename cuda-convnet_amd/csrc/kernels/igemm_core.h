@@ -120,8 +120,9 @@ struct Epi {
     unsigned wBytes;          // extent of the bit matrix in bytes
     // Sum of one operand over k, a by-product of kernels whose A or B loader is tagged SUM (weight gradients: the operand is
     // the layer's output gradient, its sum over k the bias gradient): chunk q writes sumAlpha * sum_k op(k, x) to
-    // sumOut[q * sumStride + x + g * (rowG | colG)].  Nullable.  Formed by the producer waves from the chunks they stage (Loader::add_sums),
-    // in k order, so the result does not depend on the tile shape.
+    // sumOut[q * sumStride + x + g * (rowG | colG)].  Nullable.  32x32 tiles: each consumer lane adds the k values it feeds to the MFMAs
+    // anyway, in k order (tile-independent among them).  16x16x4 tiles: the producer waves add the chunks they stage (Loader::add_sums),
+    // another fixed order: with sums asked for, the two families are chosen between by rule, never by timing.
     float* sumOut;
     long sumStride;
     float sumAlpha;
@@ -733,7 +734,8 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
                 lb.template fetch<TAB>(rb, pb, cg, g, b, kbeg + u * d.kStep, kend, j0c, jlim, tid, ktab, bcols);
             }
         };
-        constexpr bool PSA = has_sum<AADDR>::value, PSB = has_sum<BADDR>::value;
+        // (16x16x4 tiles only: the 32x32 tiles keep their sums in the consumers, where a few adds ride on 64-cycle matrix instructions)
+        constexpr bool PSA = has_sum<AADDR>::value && MF == 1, PSB = has_sum<BADDR>::value && MF == 1;
         float psa[PSA ? LA::NCH : 1], psb[PSB ? LB::NCH : 1];   // k-sum partials (launches that ask for sums have one tile per workgroup)
 #pragma unroll
         for (int it = 0; it < (PSA ? LA::NCH : 1); ++it) psa[it] = 0.f;
@@ -950,6 +952,10 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
 
     f32x16 acc[MT][NT];
 
+    constexpr bool SUMA = has_sum<AADDR>::value && KQ == 1 && MF == 0, SUMB = has_sum<BADDR>::value && KQ == 1 && MF == 0;
+    float rs[MT], cs[NT];   // SUMA / SUMB: this lane's share of the k-sums of its A rows / B columns
+    (void)rs; (void)cs;
+
     // LDS -> register fragments, software-pipelined ACROSS K steps: "slab" s holds the operands of one
     // MFMA k-step (2 k values: lane half h supplies k = kof(s) + h-dependent offset).  The reads of slab
     // s+PF are issued before the MFMAs of slab s; the last PF slabs of a K step prefetch the first PF
@@ -1131,6 +1137,14 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         for (int b = 0; b < NT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    if constexpr (SUMA) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a) rs[a] = 0.f;
+    }
+    if constexpr (SUMB) {
+#pragma unroll
+        for (int b = 0; b < NT; ++b) cs[b] = 0.f;
+    }
     for (int t = 0; t < nkTile; ++t) {
         const int nstage = stage == 2 ? 0 : stage + 1;
         STAMP(c0);
@@ -1148,6 +1162,14 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s_][a], bf[s_][b], acc[a][b], 0, 0, 0);
+            if constexpr (SUMA) {   // a handful of adds under MT * NT matrix instructions of 64 cycles each
+#pragma unroll
+                for (int a = 0; a < MT; ++a) rs[a] += af[s_][a];
+            }
+            if constexpr (SUMB) {
+#pragma unroll
+                for (int b = 0; b < NT; ++b) cs[b] += bf[s_][b];
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         // end of K step t.  No LDS wait here: every read of this stage has been consumed by an MFMA above,
@@ -1187,6 +1209,27 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
                 for (int r = 0; r < 16; ++r) acc[a][b][r] += red[((a * NT + b) * 16 + r) * 64 + lane];
             }
         __builtin_amdgcn_sched_barrier(0);
+    }
+    // k-sums: the two lane halves hold alternate groups of four k values; waves that share the operand hold copies
+    if constexpr (SUMA) {
+        if (ep.sumOut) {
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const float v = rs[a] + __shfl_xor(rs[a], 32);
+                const int i = i0 + (wm * MT + a) * 32 + l31;
+                if (ct == 0 && wn == 0 && h == 0 && i < ilim) ep.sumOut[q * ep.sumStride + i + g * ep.rowG] = ep.sumAlpha * v;
+            }
+        }
+    }
+    if constexpr (SUMB) {
+        if (ep.sumOut) {
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const float v = cs[b] + __shfl_xor(cs[b], 32);
+                const int j = coff + col_block(ct) * BN + (wn * NT + b) * 32 + l31;
+                if (blockIdx.y == 0 && wm == 0 && h == 0 && j < jlim) ep.sumOut[q * ep.sumStride + j + g * ep.colG] = ep.sumAlpha * v;
+            }
+        }
     }
     // this tile's K loop is complete: store it while the producers run ahead into the next tile
     STAMP(s0);
@@ -1246,8 +1289,8 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
     // running its tiles as one pipeline (see the kernel) instead of paying the pipeline fill per tile.
     const int stepsPerTile = ceil_div(d.kChunk < d.Kg ? d.kChunk : d.Kg, BK);
     static const bool nopersist = getenv("MC_IGEMM_NOPERSIST") != nullptr;
-    // (not when k-sums are asked for: the producers form them per workgroup, which then has exactly one tile)
-    if (KQ == 1 && !nopersist && !ep.sumOut && stepsPerTile <= 24 && (long)grid.x * grid.y * grid.z > 2L * num_cus()) {
+    // (not the 16x16x4 tiles when k-sums are asked for: their producers form them per workgroup, which then has exactly one tile)
+    if (KQ == 1 && !nopersist && !(MF && ep.sumOut) && stepsPerTile <= 24 && (long)grid.x * grid.y * grid.z > 2L * num_cus()) {
         // resident workgroups per CU at this LDS footprint (it varies with the k table): cached as (lds << 8 | count)
         const int cached = perCU[dev].load(std::memory_order_relaxed);
         int pc = (cached >> 8) == (int)(lds >> 8) ? (cached & 0xFF) : 0;
@@ -1364,16 +1407,20 @@ static const int kRowsOf[NTILES + 1] = {32, 64, 96, 160, 128, 192, 128, 128, 160
 inline int heuristic_tile4(const Dims& d, int chunks);
 // The 16x16x4 tile for a product whose WHOLE output is one such tile (75-192 rows by 129-192 columns: the dense weight gradients of
 // the cccp layers, the first conv layer's weight gradient), or -1.  A pure function of the extents: chunk plans are made with it.
-inline int whole_output_mf_tile(int Mg, int Ng) {
+// chunks: K chunks of the launch.  With too few of them for one workgroup per chunk to fill the device the output is cut in two
+// 96-row halves, then in 96 x 96 quarters.
+inline int whole_output_mf_tile(int Mg, int Ng, int chunks = 1 << 20) {
     if (!mf_whole_output(Mg, Ng)) return -1;
     if (Ng <= 160 && Mg <= 96) return M35;
-    return Mg <= 96 ? M36 : Mg <= 160 ? M56 : M66;
+    if (Mg <= 96) return M36;
+    if (4L * chunks >= 3L * num_cus()) return Mg <= 160 ? M56 : M66;
+    return 8L * chunks >= 3L * num_cus() ? M36 : M33;
 }
 // kqOk: the call site has the 96 x 192 K-split tile (long-k products).  It is taken when it cuts the padded work of the
 // 4-tile rule's pick by 15 % or more -- decided from the extents alone, see the kernel's comment.
 inline int heuristic_tile(const Dims& d, int chunks, bool kqOk = false, bool mfOk = false) {
     if (mfOk && d.batches == 1) {
-        const int m = whole_output_mf_tile(d.Mg, d.Ng);
+        const int m = whole_output_mf_tile(d.Mg, d.Ng, chunks);
         if (m >= 0) return m;
     }
     const int t = heuristic_tile4(d, chunks);
@@ -1428,6 +1475,10 @@ int launch_rows_cols_epi(const typename AADDR::P& pa, const typename BADDR::P& p
     const bool mfNow = MFOK && !nomf && !ep.bitsOut && !ep.bitsIn;
     const int rule = heuristic_tile(d, chunks, BK == 32 && EPI == EPI_PLAIN && !ep.sumOut, mfNow);   // (the K-split tile has no k-sums)
     if (rule == T33K) return launch_tile<AADDR, BADDR, BK, VEC, EPI>(rule, pa, pb, cg, d, ep, chunks, st);   // by rule only: its sum order is its own
+    // k-sums (bias gradients) are formed in one order by the 32x32 tiles and in another by the 16x16x4 tiles: with sums asked for the
+    // family is the rule's (a pure function of the shape), and the timing trials below stay inside it
+    const bool sumsFixMf = MFOK && ep.sumOut != nullptr;
+    if (sumsFixMf && is_mf_tile(rule)) return launch_tile<AADDR, BADDR, BK, VEC, EPI>(rule, pa, pb, cg, d, ep, chunks, st);
     static const char* at = getenv("MC_IGEMM_AUTOTUNE");
     static const int mode = at ? atoi(at) : 1;
     if (mode == 0) return launch_tile<AADDR, BADDR, BK, VEC, EPI>(rule, pa, pb, cg, d, ep, chunks, st);
@@ -1459,7 +1510,7 @@ int launch_rows_cols_epi(const typename AADDR::P& pa, const typename BADDR::P& p
         // skip tiles that would compute more than 4x the needed rows (a 160-row tile for a 10-row product)
         if (t != rule && (long)ceil_div(d.Mg, kRowsOf[t]) * kRowsOf[t] > 4L * ((d.Mg + 31) / 32 * 32)) continue;
         if ((t == T14 || t == T24) && d.Ng > 64) continue;   // the narrow tile only where 128 columns are mostly padding
-        if (is_mf_tile(t) && (!mfNow || d.batches != 1 || d.Ng <= 64 || d.Mg <= 32)) continue;   // 16x16x4 tiles: k-contiguous products with a wide output
+        if (is_mf_tile(t) && (!mfNow || sumsFixMf || d.batches != 1 || d.Ng <= 64 || d.Mg <= 32)) continue;   // 16x16x4 tiles: k-contiguous products with a wide output
         int rc = launch_tile<AADDR, BADDR, BK, VEC, EPI>(t, pa, pb, cg, d, ep, chunks, st);   // warm (and validates the launch)
         if (rc != MC_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
         (void)hipEventRecord(e0, st);

@@ -1,7 +1,8 @@
 set -u
-mkdir -p gpurun_out/c10
-timeout -k 10 900 python3 -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread --deselect tests/test_kernels_gpu.py > gpurun_out/c10/pytest.log 2>&1; rc=$?
-tail -4 gpurun_out/c10/pytest.log
-[ $rc -eq 0 ] || { grep -n "Error\|FAILED\|assert" gpurun_out/c10/pytest.log | tail -20; exit 1; }
-timeout -k 10 120 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-for net in 80sec 18pct conv-local imagenet; do timeout -k 10 200 python3 tools/net_bench.py $net 128 30 3 2>&1 | grep -v amdgpu | head -2; done
+mkdir -p gpurun_out/c11
+timeout -k 10 900 python3 -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread -k "tile_choice or test_gemm or weight or bias or fused or no_alloc or nin" > gpurun_out/c11/pytest.log 2>&1; rc=$?
+tail -4 gpurun_out/c11/pytest.log
+[ $rc -eq 0 ] || { grep -n "Error\|FAILED\|assert" gpurun_out/c11/pytest.log | tail -20; exit 1; }
+timeout -k 10 200 python3 tools/layer_times.py nin wgrad 2>&1 | grep wgrad
+timeout -k 10 300 python3 tools/net_bench.py imagenet 128 30 8 2>&1 | grep -v amdgpu
+timeout -k 10 200 python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline 2>/dev/null | cut -c1-200
