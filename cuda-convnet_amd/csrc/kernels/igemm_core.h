@@ -1306,8 +1306,8 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
     static const bool noswz = getenv("MC_IGEMM_NOSWZ") != nullptr;
     d.xcdSwizzle = (d.colTiles % 8 == 0 && grid.x % 8 == 0 && d.colTiles >= 16 && !noswz) ? 1 : 0;
     if (g_describeBuf) {   // dry run (mc_describe_*): which instantiation and grid this shape gets right now
-        snprintf(g_describeBuf, (size_t)g_describeLen, "mc_igemm<%s, %s, %d, %d, %d, %d, %d, %d, %d, %d, %d%s> grid=(%u,%u,%u) tile %dx%d", AADDR::tag(),
-                 BADDR::tag(), MT, NT, WM, WN, BK, VEC, NS, EPI, KQ, MF ? ", 1" : "", grid.x, grid.y, grid.z, BM, BN);
+        snprintf(g_describeBuf, (size_t)g_describeLen, "mc_igemm<%s, %s, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d> grid=(%u,%u,%u) tile %dx%d", AADDR::tag(),
+                 BADDR::tag(), MT, NT, WM, WN, BK, VEC, NS, EPI, KQ, MF, grid.x, grid.y, grid.z, BM, BN);
         return MC_OK;
     }
     hipLaunchKernelGGL(kern, grid, dim3(2 * THREADS), lds, st, pa, pb, cg, d, ep);

@@ -41,8 +41,11 @@ def step_work(layers, mb):
         elif t == "pool":
             i, o = outs(ins[0]) * mb, outs(l) * mb
             work[n + "/fwd"] = ("hbm", 4.0 * (i + o))
+            # with the dropout layer above fused in: + its output, + a keep byte per four elements (written forward, read backward)
+            work[n + "/fwd:mc_conv_local_pool_dropout"] = ("hbm", 4.0 * (i + 2 * o) + o / 4.0)
             if l["pool"] == "max":
                 work[n + "/bwd"] = ("hbm", 4.0 * (2 * i + 2 * o))         # images + maxActs + maxGrads + target
+                work[n + "/bwd:mc_conv_local_max_undo_dropout"] = ("hbm", 4.0 * (2 * i + 2 * o) + o / 4.0)
             else:
                 work[n + "/bwd:mc_conv_local_avg_undo_relu_grad"] = ("hbm", 4.0 * (2 * i + o))   # grads + relu acts + target
                 work[n + "/bwd:mc_conv_local_avg_undo"] = ("hbm", 4.0 * (i + o))

@@ -14,13 +14,13 @@ if [ "${SKIP_TESTS:-0}" != 1 ]; then
 fi
 export MC_NO_STEP_FORK=1
 B="python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/trace_nofork -o nin -- $B > $out/trace_nofork.log 2>&1; rc=$?; bad $rc
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/trace_nofork -o nin -- $B --kernel-table $out/${tag}_nin_bs128_nofork_event_table.json > $out/trace_nofork.log 2>&1; rc=$?; bad $rc
 [ $rc -eq 0 ] && python3 tools/rocprof_summary.py $(find $out/trace_nofork -name 'nin_results.db' | head -1) $out/${tag}_nin_bs128_nofork_kernel_stats.txt "MC_NO_STEP_FORK=1 rocprofv3 --kernel-trace --stats -- $B" > /dev/null
 S="python3 bench.py --steps 4 --warmup 1 --resident-minibatches 2 --no-cpu-baseline"
 pass() {  # name, counters...
   local name=$1; shift
   timeout -s KILL 200 rocprofv3 --pmc "$@" -d $out/pmc_$name -o nin -- $S > $out/pmc_$name.log 2>&1; local rc=$?; bad $rc
-  if [ $rc -eq 0 ]; then python3 tools/pmc_summary.py $(find $out/pmc_$name -name 'nin_results.db' | head -1) mc_ --out $out/${tag}_nin_bs128_nofork_pmc_$name.txt; else echo "pmc pass $name failed rc=$rc"; tail -3 $out/pmc_$name.log; fi
+  if [ $rc -eq 0 ]; then python3 tools/pmc_summary.py $(find $out/pmc_$name -name 'nin_results.db' | head -1) mc --out $out/${tag}_nin_bs128_nofork_pmc_$name.txt; else echo "pmc pass $name failed rc=$rc"; tail -3 $out/pmc_$name.log; fi
 }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
