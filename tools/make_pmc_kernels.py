@@ -5,7 +5,8 @@ profile round:
 event_table.json is bench.py --kernel-table of the kernel-trace run (profile key -> event time); kernel_stats.txt its rocprofv3
 summary split by launch shape; the two pmc files the FETCH_SIZE / WRITE_SIZE passes.  A profile key is tied to a traced launch by
 the kernel family its entry point launches (table below) and, inside the family, by the steady-state shape (>= 30 calls) whose
-traced duration is closest to the key's event time -- within 25 %, or the key gets no entry.  HBM bytes = (2 * FETCH_SIZE +
+traced duration is closest to the key's event time -- within 25 %, or the key gets no entry; keys under 25 us are left out (an
+event pair adds ~4.5 us to what it times, too much to tell small launches apart).  HBM bytes = (2 * FETCH_SIZE +
 WRITE_SIZE) * 1024 (gfx950 correction, MI355X_MICROARCH.md).  bench.py reports an entry only while its own event time for the key
 agrees with the recorded duration."""
 import json
@@ -68,7 +69,7 @@ left = dict((i, max(1, int(round(s[2] / float(per_step))))) for i, s in enumerat
 for row in sorted(json.load(open(table_f)), key=lambda r: -r["avg_ms"]):
     key, us = row["kernel"], row["avg_ms"] * 1e3
     fam = next((k for p, k in FAMILY if re.search(p, key)), None)
-    if fam is None:
+    if fam is None or us < 25.0:      # below that the event pair itself (~4.5 us) blurs which traced shape a key is
         continue
     cand = [i for i, s in enumerate(sh) if re.match(fam, s[0]) and s[2] >= 30 and left[i] > 0]
     if not cand:
