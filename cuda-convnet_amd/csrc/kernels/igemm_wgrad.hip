@@ -51,6 +51,8 @@ int conv_weight_grad_plan(int N, int C, int F, int fs, int M, int groups, int* k
     const long tiles = (long)ceil_div(rows, kRowsOf[t]) * ceil_div(fpg, kColsOf[t]) * groups;
     long chunks = num_cus() / tiles;
     if (chunks < 1) chunks = 1;
+    static const char* forced = getenv("MC_WGRAD_CHUNKS");   // tuning knob (benchmarks only)
+    if (forced && atoi(forced) > 0) chunks = atoi(forced);
     long kc = (ceil_div(K, chunks) + MC_BK_KC - 1) / MC_BK_KC * MC_BK_KC;
     if (kc < 256) kc = 256;
     if (kc > K) kc = (K + MC_BK_KC - 1) / MC_BK_KC * MC_BK_KC;

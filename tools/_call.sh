@@ -1,8 +1,12 @@
 set -u
-mkdir -p gpurun_out/c11
-timeout -k 10 900 python3 -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread -k "tile_choice or test_gemm or weight or bias or fused or no_alloc or nin" > gpurun_out/c11/pytest.log 2>&1; rc=$?
-tail -4 gpurun_out/c11/pytest.log
-[ $rc -eq 0 ] || { grep -n "Error\|FAILED\|assert" gpurun_out/c11/pytest.log | tail -20; exit 1; }
-timeout -k 10 200 python3 tools/layer_times.py nin wgrad 2>&1 | grep wgrad
-timeout -k 10 300 python3 tools/net_bench.py imagenet 128 30 8 2>&1 | grep -v amdgpu
-timeout -k 10 200 python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline 2>/dev/null | cut -c1-200
+timeout -k 10 300 python3 -u -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "pool or undo or dropout" --timeout 120 --timeout-method thread 2>&1 | tail -3 || exit 1
+for e in "" MC_POOL_NO_XCD_ORDER=1; do
+  echo "== $e"
+  env $e timeout -k 10 200 python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --kernel-table gpurun_out/kt.json > gpurun_out/b.json 2>/dev/null || exit 1
+  python3 - <<'PY'
+import json
+b=json.load(open('gpurun_out/b.json')); print(round(b['value']), b['ms_per_step'])
+for r in json.load(open('gpurun_out/kt.json')):
+    if r['kernel'].startswith('pool'): print("  %-50s %6.1f us  %.3f"%(r['kernel'], r['avg_ms']*1e3, r.get('frac_of_peak',0)))
+PY
+done
