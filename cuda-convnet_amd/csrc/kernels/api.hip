@@ -3,6 +3,9 @@
 // fp32-MFMA engine as batched products (igemm.hip: one product per module forward, one per pixel backward).
 #include <stdlib.h>
 #include <string.h>
+#include <array>
+#include <atomic>
+#include <map>
 #include <mutex>
 #include <vector>
 #include "mc_common.h"
@@ -37,6 +40,10 @@ int conv_filter_acts_impl(const float*, const float*, float*, const float*, int,
 int conv_img_acts_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int, int, int, float,
                        float, float*, int, hipStream_t);
 int conv_split_plan(int, long, int, int, int*);
+int conv_band_kind(int, int, int, int, int, int, int, int, int, int, int);
+int conv_band_launch(const float*, const float*, float*, const float*, int, int, int, int, int, int, int, int, int, int, float, unsigned*,
+                     hipStream_t);
+void describe_write(const char*);
 int conv_weight_acts_impl(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int, int, int, int,
                           float, float, float*, long, float, hipStream_t);
 int conv_weight_grad_plan(int, int, int, int, int, int, int*);
@@ -345,6 +352,9 @@ static int conv_fwd_entry(const float* images, const float* filters, float* targ
                           int numImages, int numImgColors, int imgSizeY, int imgSizeX, int numFilters, int filterSize,
                           int paddingStart, int moduleStride, int numModulesY, int numModulesX, int numGroups,
                           float scaleTargets, float scaleOutput, unsigned* reluBits, mcStream_t s);
+static std::atomic<int> g_convBand{[] { const char* e = getenv("MC_CONV_BAND"); return e ? atoi(e) : -1; }()};
+static std::map<std::array<int, 12>, int> g_bandChoice;
+static std::mutex g_bandMu;
 
 int mc_conv_filter_acts_fused(const float* images, const float* filters, float* targets, const float* biases, int neuron,
                               int numImages, int numImgColors, int imgSizeY, int imgSizeX, int numFilters, int filterSize,
@@ -394,9 +404,76 @@ static int conv_fwd_entry(const float* images, const float* filters, float* targ
             return reduce_slabs(slabs, targets, numFilters, cols, chunks, scaleOutput, scaleTargets, biases, neuron, S(s));
         }
     }
-    return conv_filter_acts_impl(images, filters, targets, biases, neuron, numImages, numImgColors, imgSizeY, imgSizeX,
-                                 numFilters, filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 0,
-                                 scaleTargets, scaleOutput, nullptr, 0, reluBits, S(s));
+    auto engine = [&]() {
+        return conv_filter_acts_impl(images, filters, targets, biases, neuron, numImages, numImgColors, imgSizeY, imgSizeX,
+                                     numFilters, filterSize, paddingStart, moduleStride, numModulesY, numModulesX, numGroups, 0,
+                                     scaleTargets, scaleOutput, nullptr, 0, reluBits, S(s));
+    };
+    // Small-filter layers (conv_band.hip): the band kernel gives the same bits as the engine, so which of the two serves a shape is
+    // decided by one timed trial per shape and device, on the caller's stream, at the first call that may be repeated
+    // (scaleTargets == 0) and may block (not under mc_set_autotune(0)).  g_convBand: -1 trial, 0 engine only, 1 band wherever it exists.
+    const int bandKind = (scaleTargets == 0.f && paddingStart <= 0 && aligned16(images) && aligned16(filters) && aligned16(targets))
+                             ? conv_band_kind(numImages, numImgColors, imgSizeY, imgSizeX, numFilters, filterSize, -paddingStart, moduleStride,
+                                              numModulesY, numModulesX, numGroups)
+                             : 0;
+    if (!bandKind || g_convBand == 0) return engine();
+    auto band = [&]() {
+        return conv_band_launch(images, filters, targets, biases, neuron, numImages, numImgColors, imgSizeY, imgSizeX, numFilters, filterSize,
+                                -paddingStart, numModulesY, numModulesX, scaleOutput, reluBits, S(s));
+    };
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const std::array<int, 12> key{numImages, numImgColors, imgSizeY, imgSizeX, numFilters, filterSize, paddingStart, numModulesY, numModulesX,
+                                  reluBits ? 1 : 0, neuron, dev};
+    int choice = g_convBand == 1 ? 1 : -1;
+    if (choice < 0) {
+        std::lock_guard<std::mutex> lk(g_bandMu);
+        auto it = g_bandChoice.find(key);
+        if (it != g_bandChoice.end()) choice = it->second;
+    }
+    if (describing()) {
+        if (choice != 1) return engine();
+        char buf[128];
+        snprintf(buf, sizeof buf, "k_conv_band kind %d (filter size, channel chunk, 32-filter blocks) tile F x (2x2 pixels x 32 images)", bandKind);
+        describe_write(buf);
+        return MC_OK;
+    }
+    if (choice == 1) return band();
+    if (choice == 0 || tune_inhibited()) return engine();
+    // the trial: the engine first (it tunes its own tile on this call), then two timed runs of each
+    int rc = engine();
+    if (rc != MC_OK) return rc;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return MC_OK;
+    float ms[2] = {1e30f, 1e30f};
+    for (int which = 0; which < 2 && rc == MC_OK; ++which) {
+        rc = which ? band() : engine();   // warm
+        if (rc != MC_OK) break;
+        (void)hipEventRecord(e0, S(s));
+        for (int r = 0; r < 2 && rc == MC_OK; ++r) rc = which ? band() : engine();
+        (void)hipEventRecord(e1, S(s));
+        float el = 0.f;
+        if (rc == MC_OK && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&el, e0, e1) == hipSuccess) ms[which] = el * 0.5f;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != MC_OK) return rc;
+    choice = ms[1] < 0.97f * ms[0] ? 1 : 0;   // the engine stays unless the band kernel is at least 3 % faster
+    static const bool verbose = getenv("MC_CONV_BAND_VERBOSE") != nullptr;
+    if (verbose)
+        fprintf(stderr, "[mc conv band] C %d %dx%d F %d N %d: engine %.1f us, band %.1f us -> %s\n", numImgColors, imgSizeY, imgSizeX, numFilters,
+                numImages, ms[0] * 1e3f, ms[1] * 1e3f, choice ? "band" : "engine");
+    {
+        std::lock_guard<std::mutex> lk(g_bandMu);
+        g_bandChoice[key] = choice;
+    }
+    return choice ? MC_OK : engine();   // the last run left the band kernel's output, which is the same bits
+}
+
+int mc_set_conv_band(int mode) {
+    MC_REQUIRE(mode >= -1 && mode <= 1, "mc_set_conv_band: mode %d (want -1 trial, 0 engine only, 1 band kernel wherever it exists)", mode);
+    g_convBand = mode;
+    return MC_OK;
 }
 
 int mc_conv_img_acts(const float* hidActs, const float* filters, float* targets, int numImages, int numImgColors,

@@ -98,6 +98,7 @@ struct Dims {
     int colB;         // column offset of batch b in the B operand and in C: b * colB
     int ktabN;        // entries of the B loader's k table in LDS (set by launch_cfg; 0 = the loader decodes k arithmetically)
     int kStep;        // distance between consecutive K tiles of one chunk (set by launch_cfg): BK, or chunks * BK when the chunks interleave
+    int stagger;      // experiment (MC_IGEMM_STAGGER=n): the second half of the grid's workgroups starts n x 8128 cycles late
 };
 
 struct Epi {
@@ -673,6 +674,11 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     const int nkTile = kil ? (d.Kg - kbeg + d.kStep - 1) / d.kStep : (kend - kbeg + BK - 1) / BK;   // K steps per tile, >= 1
     const int nk = nkTile * nTiles;                   // pipeline steps; barriers executed by every wave: 1 + nk
 
+    if (d.stagger) {   // do two co-resident workgroups that start together hurt each other (prologues and epilogues in lockstep)?
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (2 * lin >= gridDim.x * gridDim.y * gridDim.z)
+            for (int i = 0; i < d.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 #ifdef MC_ABL_STAGGER   // timing-only ablation: do the workgroups of a CU hurt each other by running in lockstep?
     if (MC_ABL_STAGGER == 1 ? ((blockIdx.x >> 3) & 1) : (2 * blockIdx.x >= gridDim.x)) {
         __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
@@ -1271,6 +1277,8 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
     }
     static const bool kInterleave = getenv("MC_IGEMM_KINTERLEAVE") != nullptr;   // experiment: interleaved K chunks for the k-contiguous products
     d.kStep = (kInterleave && AADDR::KC && BADDR::KC && chunks > 1 && d.kChunk % BK == 0 && d.Kg % BK == 0) ? chunks * BK : BK;
+    static const char* stg = getenv("MC_IGEMM_STAGGER");
+    d.stagger = stg ? atoi(stg) : 0;
     const size_t lds = ldsTile + (size_t)d.ktabN * 8;
     constexpr size_t ldsMax = has_ktab<BADDR>::value ? (ldsTile + (size_t)(KTAB_MAX + 2 * BK) * 8 <= 160 * 1024 ? ldsTile + (size_t)(KTAB_MAX + 2 * BK) * 8 : 160 * 1024) : ldsTile;
     // per-device state of this instantiation (a function attribute belongs to the device's own code object)

@@ -9,6 +9,7 @@ thread_local char* g_describeBuf = nullptr;
 thread_local int g_describeLen = 0;
 void set_describe(char* buf, int len) { g_describeBuf = buf; g_describeLen = len; }
 bool describing() { return g_describeBuf != nullptr; }
+void describe_write(const char* text) { if (g_describeBuf) snprintf(g_describeBuf, (size_t)g_describeLen, "%s", text); }
 // While set (per host thread), a shape that has not been tuned yet runs the static rule's tile instead of the timed trial.
 void set_tune_inhibit(bool on) { g_tuneInhibit = on; }
 bool tune_inhibited() { return g_tuneInhibit; }

@@ -37,6 +37,7 @@ _SIGS = {
     "mc_accumulate_f64": [c_fp, c_fp, c_i, c_fp],
     "mc_softmax_logreg": [c_fp] * 7 + [c_i, c_f, c_i, c_i, c_fp],
     "mc_set_autotune": [c_i],
+    "mc_set_conv_band": [c_i],
     "mc_conv_filter_acts_relu_bits": [c_fp] * 5 + [c_i] * 10 + [c_fp],
     "mc_gemm_relu_bits": [c_fp, c_fp, c_fp] + [c_i] * 8 + [c_fp, c_fp, c_fp],
     "mc_gemm_relu_grad_bits": [c_fp, c_fp, c_fp] + [c_i] * 8 + [c_f, c_fp, c_fp],

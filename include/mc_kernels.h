@@ -416,6 +416,13 @@ int mc_accumulate_f64(double* dst, const double* src, int n, mcStream_t stream);
  * mc_set_autotune(0) switches that off for the calling thread (a shape not tuned yet runs the static rule's tile: same bits),
  * mc_set_autotune(1) back on: for callers that are capturing a HIP graph or otherwise must not block.  Returns MC_OK. */
 int mc_set_autotune(int enabled);
+/* convFilterActs (Kernel/src/conv/filter_acts.cu:2206-2211) has a second kernel family for small-filter layers -- stride 1, one
+ * group, 5x5 filters, numImages a multiple of 32, and either 3 input channels with 32 / 64 / 192 filters or 32 filters over a multiple
+ * of 8 channels: the input band of a 2x2-pixel output block is staged in LDS once and all 25 taps are formed from it
+ * (csrc/kernels/conv_band.hip).  It returns the same bits as the general engine, so the choice is made by one timed trial per
+ * shape, like the tile choice above.  mode -1: that trial (default; MC_CONV_BAND in the environment sets the initial mode),
+ * 0: general engine only, 1: the band kernel wherever it exists.  Process-wide.  No counterpart in the reference. */
+int mc_set_conv_band(int mode);
 
 /* ---------------- softmax / logistic regression cost ----------------
  * SoftmaxLayer::fpropActs (Kernel/src/layers/layer.cu:612-622, five NVMatrix ops there),

@@ -72,6 +72,51 @@ def test_conv_triplet(N, C, H, fs, F, pad, stride, groups):
         assert relerr(host(dw), expw) < TOL, ps
 
 
+BAND_CASES = [
+    # N, C, H, F, pad, modules (stride 1, 5x5): the shapes conv_band.hip serves, plus ragged edges
+    (128, 3, 32, 32, 2, 32),     # layers-80sec conv1
+    (128, 32, 16, 32, 2, 16),    # layers-80sec conv2
+    (128, 3, 32, 192, 2, 32),    # NIN conv1
+    (64, 3, 24, 64, 2, 24),      # cifar-cropped first layer, 64 filters
+    (32, 16, 21, 32, 2, 21),     # odd map: the last 2x2 block hangs over the edge; two channel chunks
+    (96, 8, 20, 32, 0, 16),      # no padding, one chunk, three image blocks
+    (64, 3, 30, 32, 4, 34),      # more padding than the filter needs
+]
+
+
+@pytest.mark.parametrize("N,C,H,F,pad,M", BAND_CASES)
+def test_conv_band_kernel_gives_the_engines_bits(N, C, H, F, pad, M):
+    """conv_band.hip against the oracle, and bit for bit against the general engine (same MFMA, same k order, same epilogue):
+    plain, with bias + relu, and with the relu bit mask."""
+    import torch
+    m = mc()
+    rng = np.random.default_rng(21)
+    fs = 5
+    img = rng.standard_normal((C * H * H, N)).astype(np.float32)
+    W = rng.standard_normal((C * fs * fs, F)).astype(np.float32)
+    b = rng.standard_normal((F,)).astype(np.float32)
+    dimg, dW, db = dev(img), dev(W), dev(b)
+    geo = (N, C, H, H, F, fs, -pad, 1, M, M, 1)
+    exp = G.filter_acts(img, W, *geo)
+    words = m.lib().mc_relu_bits_words(F, M * M * N)
+    got = {}
+    try:
+        for mode in (0, 1):
+            m.call("mc_set_conv_band", mode)
+            plain, fused, rb = nans(F * M * M, N), nans(F * M * M, N), nans(F * M * M, N)
+            bits = torch.zeros(words, dtype=torch.int32, device="cuda")
+            m.call("mc_conv_filter_acts", ptr(dimg), ptr(dW), ptr(plain), *geo, 0.0, 0.5, None)
+            m.call("mc_conv_filter_acts_fused", ptr(dimg), ptr(dW), ptr(fused), ptr(db), m.NEURON_RELU, *geo, 0.0, 1.0, None)
+            m.call("mc_conv_filter_acts_relu_bits", ptr(dimg), ptr(dW), ptr(rb), ptr(db), ptr(bits), *geo[:-1], None)
+            got[mode] = (host(plain), host(fused), host(rb), bits.cpu().numpy())
+    finally:
+        m.call("mc_set_conv_band", -1)
+    assert relerr(got[1][0], 0.5 * exp) < TOL
+    assert relerr(got[1][1], np.maximum(exp + b.repeat(M * M)[:, None], 0)) < TOL
+    for x, y, what in zip(got[0], got[1], ("plain", "bias + relu", "relu + bits: values", "relu + bits: mask")):
+        assert np.array_equal(x, y), what
+
+
 def test_conv_fused_bias_relu_is_bitwise_unfused():
     m = mc()
     rng = np.random.default_rng(12)
