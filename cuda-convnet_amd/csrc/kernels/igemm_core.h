@@ -406,15 +406,48 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsi
 // PERM (k-contiguous operands of the 16x16x4 tiles): the four k values of a 16-byte chunk are stored as (k0, k2 | k1, k3) in even
 // chunks of a row and (k1, k3 | k0, k2) in odd ones, so that a consumer lane reads the two values it feeds to a group's two matrix
 // instructions with ONE ds_read_b64 and no select (see the MF consumer).
-template <class ADDR, int ROWS, int BK, int VEC, bool PERM = false>
+// TR (operands contiguous along their row axis, "NAT"): the tile is TRANSPOSED on its way into LDS, so that the consumers read
+// the four k values of a row's k-quad with one ds_read_b128 -- four slabs per read, as for the k-contiguous operands -- instead
+// of one ds_read_b32 per slab.  (Timing ablation MC_ABL_NOLDSREAD: without their fragment reads the consumers of NIN's forward
+// products finish 8-14 % sooner -- conv2 forward 271 -> 240 us -- so a read instruction saved is matrix-pipe time won.)  A thread
+// gathers a UNIT = 4 consecutive k x 4 consecutive x (four 16-byte loads, lanes running along x: coalesced as before) and
+// writes four (k0..k3) quads.  LDS float4 index of (k-quad kq, row x): kq * 4 QP + (x & 3) * QP + (x >> 2) -- the rows are
+// dealt out over four quarters so that the lanes of a wave, which hold consecutive x-quads, write consecutive float4s (no bank
+// conflict: ds_write_b128 is served in groups of 8 contiguous lanes), and the quarter pitch QP = 4 (mod 8) float4s makes the
+// consumers' reads conflict-free too: ds_read_b128 is served in the 16-lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+ 32)
+// over 16 slots of 16 bytes; lane l31 reads slot (l31 & 3) QP + (l31 >> 2) + const, and with QP = 4 or 12 (mod 16) the sixteen
+// (l31 & 3, l31 >> 2) pairs of a group land on sixteen different slots (MI355X_MICROARCH.md, LDS; QP = 2 (mod 8) was measured
+// first: SQ_LDS_BANK_CONFLICT 30 % of the LDS cycles, every product slower than with ds_read_b32).
+template <class ADDR, int ROWS, int BK, int VEC, bool PERM = false, bool TR = false>
 struct Loader {
     typedef typename ADDR::P P;
+    static_assert(!TR || (!ADDR::KC && !PERM && BK % 4 == 0 && ROWS % 32 == 0), "the transposing form is for row-contiguous operands");
     static constexpr bool KC = ADDR::KC;
+    static constexpr bool TRANSPOSED = TR;
+    static constexpr bool LKC = KC || TR;   // LDS holds k-quads per row (read with b128 / b64), not [k][rows]
     static constexpr int ROWSP = ROWS + 1;
-    static constexpr int LDS_FLOATS = KC ? (BK / 4) * ROWSP * 4 : BK * ROWS;
+    static constexpr int QP = (ROWS / 4 + 3) / 8 * 8 + 4;   // the least QP >= ROWS / 4 with QP % 8 == 4
+    static constexpr int LDS_FLOATS = TR ? (BK / 4) * 4 * QP * 4 : KC ? (BK / 4) * ROWSP * 4 : BK * ROWS;
     static constexpr int CHUNKS = BK * ROWS / 4;
-    static constexpr int NCH = (CHUNKS + THREADS - 1) / THREADS;
-    float4 r[NCH];
+    static constexpr int UNITS = (BK / 4) * (ROWS / 4);
+    static constexpr int NU = (UNITS + THREADS - 1) / THREADS;
+    static constexpr int NCH = TR ? 4 * NU : (CHUNKS + THREADS - 1) / THREADS;
+    static constexpr int NCOL = TR ? NU : NCH;   // distinct columns among a thread's chunks (K-table loaders)
+    // (the chunk registers r[NCH] belong to the caller: a producer thread that serves ONE operand keeps one set for whichever it is)
+
+    // register `it` of thread tid -> (k offset, x offset) of its chunk inside the tile, and whether the chunk exists
+    __device__ static __forceinline__ void pos(int it, int tid, int& dk, int& dx, bool& live) {
+        if (TR) {
+            const int u = tid + (it >> 2) * THREADS;
+            live = UNITS % THREADS == 0 || u < UNITS;
+            dk = (u / (ROWS / 4)) * 4 + (it & 3);
+            dx = (u % (ROWS / 4)) * 4;
+        } else {
+            const int c = tid + it * THREADS;
+            live = CHUNKS % THREADS == 0 || c < CHUNKS;
+            chunk_pos(c, dk, dx);
+        }
+    }
 
     // chunk c -> (k offset inside tile, x offset inside tile) of its first element
     __device__ static __forceinline__ void chunk_pos(int c, int& dk, int& dx) {
@@ -432,14 +465,14 @@ struct Loader {
     __device__ static __forceinline__ void prep_cols(KCol* cols, const P& p, const ConvG& cg, int g, int x0, int xlim, int tid) {
         if constexpr (has_ktab<ADDR>::value) {
 #pragma unroll
-            for (int it = 0; it < NCH; ++it) {
-                const int c = tid + it * THREADS;
+            for (int ic = 0; ic < NCOL; ++ic) {
                 int dk, dx;
-                chunk_pos(c, dk, dx);
+                bool live;
+                pos(TR ? 4 * ic : ic, tid, dk, dx, live);
                 const int x = x0 + dx;
                 KCol col = ADDR::ktab_col(p, cg, g, x);
-                if (!((x < xlim) & (CHUNKS % THREADS == 0 || c < CHUNKS))) col.cy = KCOL_DEAD;
-                cols[it] = col;
+                if (!((x < xlim) & live)) col.cy = KCOL_DEAD;
+                cols[ic] = col;
             }
         }
     }
@@ -448,7 +481,7 @@ struct Loader {
     // compiler's vmcnt bookkeeping must stay exact -- with the branch it waited for vmcnt(3) instead of vmcnt(6) before every
     // commit and drained to vmcnt(0) in the arithmetic path, i.e. one tile in flight instead of three)
     template <bool TAB = false>
-    __device__ __forceinline__ void fetch(__amdgpu_buffer_rsrc_t rs, const P& p, const ConvG& cg, int g, int b, int k0, int kend,
+    __device__ static __forceinline__ void fetch(float4* r, __amdgpu_buffer_rsrc_t rs, const P& p, const ConvG& cg, int g, int b, int k0, int kend,
                                           int x0, int xlim, int tid, const int2* ktab = nullptr, const KCol* cols = nullptr) {
 #ifdef MC_ABL_NOFETCH   // timing-only ablation builds (tools/build_variant.sh); wrong results
         if (k0 > 0) return;
@@ -462,27 +495,28 @@ struct Loader {
 #pragma unroll
                 for (int it = 0; it < NCH; ++it) {
                     int dk, dx;
-                    chunk_pos(tid + it * THREADS, dk, dx);
+                    bool live;
+                    pos(it, tid, dk, dx, live);
                     ent[it] = ktab[k0 + dk];   // the table is padded to a whole K tile
                 }
 #pragma unroll
                 for (int it = 0; it < NCH; ++it) asm volatile("" : "+v"(ent[it].x), "+v"(ent[it].y));
 #pragma unroll
                 for (int it = 0; it < NCH; ++it) {
-                    const int c = tid + it * THREADS;
                     int dk, dx;
-                    chunk_pos(c, dk, dx);
+                    bool live;
+                    pos(it, tid, dk, dx, live);
                     const int k = k0 + dk;
                     const int2 e = ent[it];
                     const int dy = (int)(short)(e.y & 0xFFFF), dxx = e.y >> 16;
                     if (VEC == 4) {   // the column part was decoded once per tile (prep_cols)
-                        const bool ok = ((unsigned)(cols[it].cy + dy) < limY) & ((unsigned)(cols[it].cx + dxx) < limX) & (k < kend);
-                        unsigned off = (unsigned)(cols[it].base + e.x) * 4u;
+                        const KCol& cl = cols[TR ? it >> 2 : it];
+                        const bool ok = ((unsigned)(cl.cy + dy) < limY) & ((unsigned)(cl.cx + dxx) < limX) & (k < kend);
+                        unsigned off = (unsigned)(cl.base + e.x) * 4u;
                         off = ok ? off : OOB;
                         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
                         r[it] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
                     } else {
-                        const bool live = CHUNKS % THREADS == 0 || c < CHUNKS;
                         const int x = x0 + dx;
                         float ev[4];
 #pragma unroll
@@ -528,10 +562,9 @@ struct Loader {
         }
 #pragma unroll
         for (int it = 0; it < NCH; ++it) {
-            const int c = tid + it * THREADS;
-            const bool live = CHUNKS % THREADS == 0 || c < CHUNKS;
             int dk, dx;
-            chunk_pos(c, dk, dx);
+            bool live;
+            pos(it, tid, dk, dx, live);
             const int k = k0 + dk, x = x0 + dx;
             if (VEC == 4) {
                 int off;
@@ -557,7 +590,7 @@ struct Loader {
     // BK / 4 partials sit in consecutive lanes and are combined when the K loop is over (sum_rows).  The order depends on BK and on
     // the K chunks only, not on the tile.  The producers have the time: the consumers' matrix instructions do not overlap with
     // their own vector instructions (tools/census/mfma16_probe.hip: 2 VALU per 16x16x4 MFMA cost 6.8 of its 32 cycles).
-    __device__ __forceinline__ void add_sums(float* ps) const {
+    __device__ static __forceinline__ void add_sums(const float4* r, float* ps) {
         static_assert(KC, "k-sums come with k-contiguous operands");
 #pragma unroll
         for (int it = 0; it < NCH; ++it) { ps[it] += r[it].x; ps[it] += r[it].y; ps[it] += r[it].z; ps[it] += r[it].w; }
@@ -576,11 +609,34 @@ struct Loader {
             if ((CHUNKS % THREADS == 0 || c < CHUNKS) && (c % (BK / 4)) == 0 && x < xlim) out[x] = alpha * v;
         }
     }
-    __device__ __forceinline__ void commit(float* lds, int tid) const {
+    __device__ static __forceinline__ void commit(const float4* r, float* lds, int tid) {
 #ifdef MC_ABL_NOCOMMIT
         return;
 #endif
         float4* l4 = reinterpret_cast<float4*>(lds);
+        if constexpr (TR) {
+#pragma unroll
+            for (int iu = 0; iu < NU; ++iu) {
+                int dk, dx;
+                bool live;
+                pos(4 * iu, tid, dk, dx, live);
+                // The regrouping below (four registers of four different loads into one 16-byte store) is register copies.  Left
+                // alone the compiler schedules them right behind the loads -- and with them a wait for the loads just issued, every
+                // K step: one tile in flight instead of three.  The empty asm "rewrites" the loaded values HERE, so whatever
+                // reads them, copies included, stays behind this point.
+                float4 a = r[4 * iu], b = r[4 * iu + 1], c = r[4 * iu + 2], d = r[4 * iu + 3];   // k0 .. k3 at x .. x+3
+                asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
+                asm volatile("" : "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w), "+v"(d.x), "+v"(d.y), "+v"(d.z), "+v"(d.w));
+                if (live) {
+                    float4* q = l4 + (dk >> 2) * 4 * QP + (dx >> 2);
+                    q[0] = make_float4(a.x, b.x, c.x, d.x);
+                    q[QP] = make_float4(a.y, b.y, c.y, d.y);
+                    q[2 * QP] = make_float4(a.z, b.z, c.z, d.z);
+                    q[3 * QP] = make_float4(a.w, b.w, c.w, d.w);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < NCH; ++it) {
             const int c = tid + it * THREADS;
@@ -630,6 +686,17 @@ __device__ __forceinline__ void lds_done_barrier() {
 // k-contiguous, plain epilogue.  The k values of an 8-group go to the matrix pipe in the order of the 32x32x2 path
 // (0,4,1,5,2,6,3,7: lane group q of MFMA m takes k = 4 (q & 1) + 2 m + (q >> 1)), and the result of either instruction is one
 // k-ordered fma chain, so these tiles give the same bits as every other tile for the same K chunks.
+// Which row-contiguous operands take the transposing loader: all, except in the 160-row tile -- that one is held at 128
+// registers for two resident workgroups per CU and has none to spare for four chunks per producer thread and operand -- and only on the vector path (the scalar path,
+// odd batch sizes, would take 175 registers).
+#ifndef MC_TR_NAT   // off by default: see the measurements in DESIGN.md (the consumers gain 11 %, the producers lose more)
+template <class ADDR> constexpr bool tr_nat(int, int, int) { return false; }
+#else
+template <class ADDR> constexpr bool tr_nat(int rows, int other, int vec) { return !ADDR::KC && vec == 4 && rows % 32 == 0 && rows != 160 && other != 160; }
+#endif
+template <class ADDR, int ROWS, int OTHER, int BK, int VEC, bool PERM = false>
+using LoaderT = Loader<ADDR, ROWS, BK, VEC, PERM, tr_nat<ADDR>(ROWS, OTHER, VEC)>;
+
 template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC, int NS, int EPI, int KQ, int MF = 0>
 __global__ void __launch_bounds__(2 * THREADS)
 #ifndef MC_NO_T51_CAP   // the 160-row tile sits 3-17 registers above 128 = two resident workgroups per CU: cap it (a few spills outside the K loop)
@@ -643,8 +710,8 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     static_assert(MF == 0 || (KQ == 1 && EPI == EPI_PLAIN && AADDR::KC && BADDR::KC && BK % 8 == 0), "16x16x4 tiles: k-contiguous operands, plain epilogue");
     constexpr int UNIT = MF ? 16 : 32;
     constexpr int BM = UNIT * MT * WM, BN = UNIT * NT * WN;
-    typedef Loader<AADDR, BM, BK, VEC, MF == 1> LA;
-    typedef Loader<BADDR, BN, BK, VEC, MF == 1> LB;
+    typedef LoaderT<AADDR, BM, BN, BK, VEC, MF == 1> LA;
+    typedef LoaderT<BADDR, BN, BM, BK, VEC, MF == 1> LB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // three LDS stages, stage s = [A tile | B tile]: during K step t the consumers read stage t % 3 (and,
     // near its end, prefetch the first fragments of stage (t+1) % 3, complete since the previous barrier)
@@ -709,35 +776,53 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         __builtin_amdgcn_s_setprio(3);
 #endif
         const __amdgpu_buffer_rsrc_t ra = make_rsrc(AADDR::base(pa), pa.bytes), rb = make_rsrc(BADDR::base(pb), pb.bytes);
-        auto produce = [&](auto persist_, auto tab_) {
+        // Register sets.  When both operands take the transposing loader and their units fit the 256 producer threads side by
+        // side, a thread serves ONE operand -- waves [0, TA / 64) gather A units, the others B units -- and a set is the four
+        // chunks of that one unit (serving both would double the ring: 146 registers, one workgroup per CU).  The role is a
+        // compile-time property of the producer instance (ROLE 1 = A, 2 = B, 0 = both), chosen once, outside the K loop: as a
+        // branch inside it the compiler lost its exact vmcnt bookkeeping and drained the loads in flight every third step.
+        constexpr int TA = (LA::UNITS + 63) / 64 * 64;
+        constexpr bool SPLIT = LA::TRANSPOSED && LB::TRANSPOSED && LA::NU == 1 && LB::NU == 1 && TA + LB::UNITS <= THREADS;
+        auto produce = [&](auto persist_, auto tab_, auto role_) {
         constexpr bool PERSIST = decltype(persist_)::value;
         constexpr bool TAB = decltype(tab_)::value;   // the B loader reads the k part of its addresses from the LDS table
-        LA as[NS];
-        LB bs[NS];
+        constexpr int ROLE = decltype(role_)::value;
+        struct SetBoth { float4 a[LA::NCH]; float4 b[LB::NCH]; };
+        struct SetOne { float4 r[4]; };
+        typename std::conditional<ROLE != 0, SetOne, SetBoth>::type as[NS];
         // Persistent workers (several column tiles per workgroup): fetches are issued in step order (u = 0, 1, 2, ...),
         // so the (tile, K position) of the next one is a running pair of workgroup-uniform counters rather than a
         // division of u.  One tile per workgroup (PERSIST false): the column origin is a loop invariant and the
         // loaders' per-column decode stays hoisted out of the K loop (conv2 backward-data is bound by this arithmetic).
         int fk = 0, fj0 = coff + col_block(blockIdx.x) * BN, ft = blockIdx.x;
         const int j0c = fj0;
-        KCol bcols[LB::NCH];   // K-table loaders: the column part of this thread's chunks of the current tile
-        if (TAB && VEC == 4) LB::prep_cols(bcols, pb, cg, g, fj0, jlim, tid);
-        auto fetch = [&](auto& la, auto& lb, int u) {
+        KCol bcols[LB::NCOL];   // K-table loaders: the column part of this thread's chunks of the current tile
+        const int tidB = ROLE == 2 ? tid - TA : tid;
+        auto prep = [&](int j0) {
+            if (TAB && VEC == 4 && ROLE != 1) LB::prep_cols(bcols, pb, cg, g, j0, jlim, tidB);
+        };
+        prep(fj0);
+        auto fetch_at = [&](auto& set, int k0, int j0) {
+            if constexpr (ROLE == 1) {
+                LA::fetch(set.r, ra, pa, cg, g, b, k0, kend, i0, ilim, tid);
+            } else if constexpr (ROLE == 2) {
+                LB::template fetch<TAB>(set.r, rb, pb, cg, g, b, k0, kend, j0, jlim, tidB, ktab, bcols);
+            } else {
+                LA::fetch(set.a, ra, pa, cg, g, b, k0, kend, i0, ilim, tid);
+                LB::template fetch<TAB>(set.b, rb, pb, cg, g, b, k0, kend, j0, jlim, tid, ktab, bcols);
+            }
+        };
+        auto fetch = [&](auto& set, int u) {
             if (PERSIST) {
-#ifdef MC_ABL_A_ONCE   // timing-only ablation: the A operand is fetched for a worker's first column tile only (wrong results)
-                if (ft == (int)blockIdx.x)
-#endif
-                la.fetch(ra, pa, cg, g, b, kbeg + fk * d.kStep, kend, i0, ilim, tid);
-                lb.template fetch<TAB>(rb, pb, cg, g, b, kbeg + fk * d.kStep, kend, fj0, jlim, tid, ktab, bcols);
+                fetch_at(set, kbeg + fk * d.kStep, fj0);
                 if (++fk == nkTile) {
                     fk = 0;
                     ft += gridDim.x;
                     fj0 = coff + col_block(ft) * BN;
-                    if (TAB && VEC == 4) LB::prep_cols(bcols, pb, cg, g, fj0, jlim, tid);
+                    prep(fj0);
                 }
             } else {
-                la.fetch(ra, pa, cg, g, b, kbeg + u * d.kStep, kend, i0, ilim, tid);
-                lb.template fetch<TAB>(rb, pb, cg, g, b, kbeg + u * d.kStep, kend, j0c, jlim, tid, ktab, bcols);
+                fetch_at(set, kbeg + u * d.kStep, j0c);
             }
         };
         // (16x16x4 tiles only: the 32x32 tiles keep their sums in the consumers, where a few adds ride on 64-cycle matrix instructions)
@@ -747,23 +832,29 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         for (int it = 0; it < (PSA ? LA::NCH : 1); ++it) psa[it] = 0.f;
 #pragma unroll
         for (int it = 0; it < (PSB ? LB::NCH : 1); ++it) psb[it] = 0.f;
-        auto commit = [&](const auto& la, const auto& lb, int stage) {
-            la.commit(smem + stage * STAGE, tid);
-            lb.commit(smem + stage * STAGE + LA::LDS_FLOATS, tid);
-            if constexpr (PSA) la.add_sums(psa);
-            if constexpr (PSB) lb.add_sums(psb);
+        auto commit = [&](const auto& set, int stage) {
+            if constexpr (ROLE == 1) {
+                LA::commit(set.r, smem + stage * STAGE, tid);
+            } else if constexpr (ROLE == 2) {
+                LB::commit(set.r, smem + stage * STAGE + LA::LDS_FLOATS, tidB);
+            } else {
+                LA::commit(set.a, smem + stage * STAGE, tid);
+                LB::commit(set.b, smem + stage * STAGE + LA::LDS_FLOATS, tid);
+                if constexpr (PSA) LA::add_sums(set.a, psa);
+                if constexpr (PSB) LB::add_sums(set.b, psb);
+            }
         };
 #pragma unroll
         for (int u = 0; u < NS; ++u)
-            if (u < nk) fetch(as[u], bs[u], u);
+            if (u < nk) fetch(as[u], u);
         // per-row bias of this tile -> LDS (behind the three stages), so the epilogue does not wait on one global load
         // per output row; visible to the consumers through the first barrier
         if (tid < BM) smem[3 * STAGE + tid] = (ep.bias && i0 + tid < d.Mg) ? ep.bias[i0 + tid + g * ep.rowG] : 0.f;
-        commit(as[0], bs[0], 0);
-        if (NS < nk) fetch(as[0], bs[0], NS);
+        commit(as[0], 0);
+        if (NS < nk) fetch(as[0], NS);
         if (1 < nk) {
-            commit(as[1 % NS], bs[1 % NS], 1);
-            if (NS + 1 < nk) fetch(as[1 % NS], bs[1 % NS], NS + 1);
+            commit(as[1 % NS], 1);
+            if (NS + 1 < nk) fetch(as[1 % NS], NS + 1);
         }
         lds_done_barrier();   // tiles 0 and 1 visible
         int t = 0, stage = 2; // stage of tile t+2
@@ -775,9 +866,9 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
             for (int j = 0; j < NS; ++j) {
                 const int u = t + j + 2;                 // tile written during K step t+j; set (j+2) % NS
                 STAMP(p0);
-                commit(as[(j + 2) % NS], bs[(j + 2) % NS], stage);
+                commit(as[(j + 2) % NS], stage);
                 STAMP(p1);
-                fetch(as[(j + 2) % NS], bs[(j + 2) % NS], u + NS);
+                fetch(as[(j + 2) % NS], u + NS);
                 STAMP(p2);
                 stage = stage == 2 ? 0 : stage + 1;
 #ifdef MC_STAMP
@@ -804,8 +895,8 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
                 const int tt = t + j, u = tt + 2;
                 if (tt < nk) {
                     if (u < nk) {
-                        commit(as[(j + 2) % NS], bs[(j + 2) % NS], stage);
-                        if (u + NS < nk) fetch(as[(j + 2) % NS], bs[(j + 2) % NS], u + NS);
+                        commit(as[(j + 2) % NS], stage);
+                        if (u + NS < nk) fetch(as[(j + 2) % NS], u + NS);
                     }
                     stage = stage == 2 ? 0 : stage + 1;
                     lds_done_barrier();   // end of K step tt
@@ -819,16 +910,24 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
             if (ep.sumOut && blockIdx.y == 0) LB::sum_rows(psb, ep.sumOut + q * ep.sumStride + g * ep.colG, ep.sumAlpha, j0c, jlim, tid);
         }
         };
+        auto produce_roles = [&](auto persist_, auto tab_) {
+            if constexpr (SPLIT) {
+                if (__builtin_amdgcn_readfirstlane(tid >> 6) < TA / 64) produce(persist_, tab_, std::integral_constant<int, 1>{});
+                else produce(persist_, tab_, std::integral_constant<int, 2>{});
+            } else {
+                produce(persist_, tab_, std::integral_constant<int, 0>{});
+            }
+        };
         const bool onePerTile = (int)gridDim.x == d.colTiles;
         if constexpr (has_ktab<BADDR>::value) {
             if (ktab) {
-                if (onePerTile) produce(std::false_type{}, std::true_type{});
-                else produce(std::true_type{}, std::true_type{});
+                if (onePerTile) produce_roles(std::false_type{}, std::true_type{});
+                else produce_roles(std::true_type{}, std::true_type{});
                 return;
             }
         }
-        if (onePerTile) produce(std::false_type{}, std::false_type{});
-        else produce(std::true_type{}, std::false_type{});
+        if (onePerTile) produce_roles(std::false_type{}, std::false_type{});
+        else produce_roles(std::true_type{}, std::false_type{});
         return;
     }
 
@@ -969,42 +1068,69 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     constexpr int SLABS = BK / 2 / KQ, PF = 2;   // slabs of a K step this wave multiplies (its half when KQ == 2)
     static_assert(SLABS >= 4 + PF && SLABS % 4 == 0, "prefetch into consumed fragment registers");
     float af[SLABS][MT], bf[SLABS][NT];
+#ifdef MC_ABL_NOLDSREAD   // timing-only ablation: the consumers read no fragments (what do their LDS reads cost the MFMA stream?)
+    float ablv = 1.f;
+    asm volatile("" : "+v"(ablv));
+#endif
     auto load_slab = [&](const float* cA, const float* cB, int s_) {
         // slab s_ (of this wave's part of the tile) = (k8, e): k = k8*8 + 4*h + e.  NAT operands read one float per slab; KC
         // operands fetch the four slabs of a k8 group with one ds_read_b128 when e == 0.
+#ifdef MC_ABL_NOLDSREAD
+        for (int a = 0; a < MT; ++a) af[s_][a] = ablv;
+        for (int b = 0; b < NT; ++b) bf[s_][b] = ablv;
+        return;
+#endif
         const int k8 = (s_ >> 2) + kq * (SLABS / 4), e = s_ & 3;
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
             const int row = (wm * MT + a) * 32 + l31;
-            if (LA::KC) {
+            if (LA::LKC) {
+                // float4 index of (k-quad, row): k-contiguous loaders [quad][ROWS + 1], transposing loaders quarters of pitch QP
+                const int qi = LA::KC ? (k8 * 2 + h) * LA::ROWSP + row : (k8 * 2 + h) * 4 * LA::QP + (l31 & 3) * LA::QP + (wm * MT + a) * 8 + (l31 >> 2);
                 if (MT >= 5 || KQ == 2) {   // tall / 3x3 wave tiles: two b64 reads per k8 group halve the fragment registers in flight
                     if ((e & 1) == 0) {
-                        const float2 v = reinterpret_cast<const float2*>(cA)[((k8 * 2 + h) * LA::ROWSP + row) * 2 + (e >> 1)];
+                        const float2 v = reinterpret_cast<const float2*>(cA)[qi * 2 + (e >> 1)];
                         af[s_][a] = v.x; af[s_ + 1][a] = v.y;
                     }
                 } else if (e == 0) {
-                    const float4 v = reinterpret_cast<const float4*>(cA)[(k8 * 2 + h) * LA::ROWSP + row];
+                    const float4 v = reinterpret_cast<const float4*>(cA)[qi];
                     af[s_][a] = v.x; af[s_ + 1][a] = v.y; af[s_ + 2][a] = v.z; af[s_ + 3][a] = v.w;
                 }
             } else {
+#ifdef MC_NO_READ2   // A/B switch: one ds_read_b32 per slab
                 af[s_][a] = cA[(k8 * 8 + 4 * h + e) * BM + row];
+#else
+                // slabs e and e + 1 of a lane half are consecutive k: BM floats apart, one ds_read2_b32 for the pair
+                if ((e & 1) == 0) {
+                    af[s_][a] = cA[(k8 * 8 + 4 * h + e) * BM + row];
+                    af[s_ + 1][a] = cA[(k8 * 8 + 4 * h + e + 1) * BM + row];
+                }
+#endif
             }
         }
 #pragma unroll
         for (int b = 0; b < NT; ++b) {
             const int col = (wn * NT + b) * 32 + l31;
-            if (LB::KC) {
+            if (LB::LKC) {
+                const int qi = LB::KC ? (k8 * 2 + h) * LB::ROWSP + col : (k8 * 2 + h) * 4 * LB::QP + (l31 & 3) * LB::QP + (wn * NT + b) * 8 + (l31 >> 2);
                 if (KQ == 2) {
                     if ((e & 1) == 0) {
-                        const float2 v = reinterpret_cast<const float2*>(cB)[((k8 * 2 + h) * LB::ROWSP + col) * 2 + (e >> 1)];
+                        const float2 v = reinterpret_cast<const float2*>(cB)[qi * 2 + (e >> 1)];
                         bf[s_][b] = v.x; bf[s_ + 1][b] = v.y;
                     }
                 } else if (e == 0) {
-                    const float4 v = reinterpret_cast<const float4*>(cB)[(k8 * 2 + h) * LB::ROWSP + col];
+                    const float4 v = reinterpret_cast<const float4*>(cB)[qi];
                     bf[s_][b] = v.x; bf[s_ + 1][b] = v.y; bf[s_ + 2][b] = v.z; bf[s_ + 3][b] = v.w;
                 }
             } else {
+#ifdef MC_NO_READ2
                 bf[s_][b] = cB[(k8 * 8 + 4 * h + e) * BN + col];
+#else
+                if ((e & 1) == 0) {
+                    bf[s_][b] = cB[(k8 * 8 + 4 * h + e) * BN + col];
+                    bf[s_ + 1][b] = cB[(k8 * 8 + 4 * h + e + 1) * BN + col];
+                }
+#endif
             }
         }
     };
@@ -1262,8 +1388,8 @@ template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int 
 int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const ConvG& cg, const Dims& d0,
                const Epi& ep, int chunks, hipStream_t st) {
     constexpr int BM = (MF ? 16 : 32) * MT * WM, BN = (MF ? 16 : 32) * NT * WN;
-    typedef Loader<AADDR, BM, BK, VEC> LA;
-    typedef Loader<BADDR, BN, BK, VEC> LB;
+    typedef LoaderT<AADDR, BM, BN, BK, VEC> LA;
+    typedef LoaderT<BADDR, BN, BM, BK, VEC> LB;
     constexpr size_t ldsTile = (3 * (LA::LDS_FLOATS + LB::LDS_FLOATS) + BM) * sizeof(float);   // three stages + the tile's bias column
     static_assert(ldsTile <= 160 * 1024, "LDS budget");
     auto kern = mc_igemm<AADDR, BADDR, MT, NT, WM, WN, BK, VEC, NS, EPI, KQ, MF>;
@@ -1342,7 +1468,7 @@ inline bool is_mf_tile(int t) { return t >= M56 && t <= M33; }
 // only the tiles that still fit 160 KB; launch_tile maps the others to the nearest one that does.
 template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC, int UNIT = 32>
 constexpr bool tile_fits() {
-    return (3 * (size_t)(Loader<AADDR, UNIT * MT * WM, BK, VEC>::LDS_FLOATS + Loader<BADDR, UNIT * NT * WN, BK, VEC>::LDS_FLOATS) + UNIT * MT * WM) * sizeof(float) <= 160 * 1024;
+    return (3 * (size_t)(LoaderT<AADDR, UNIT * MT * WM, UNIT * NT * WN, BK, VEC>::LDS_FLOATS + LoaderT<BADDR, UNIT * NT * WN, UNIT * MT * WM, BK, VEC>::LDS_FLOATS) + UNIT * MT * WM) * sizeof(float) <= 160 * 1024;
 }
 // the 16x16x4 tiles exist for these products only
 template <class AADDR, class BADDR, int BK, int EPI>
