@@ -431,13 +431,18 @@ struct Loader {
     static constexpr int CHUNKS = BK * ROWS / 4;
     static constexpr int UNITS = (BK / 4) * (ROWS / 4);
     static constexpr int NU = (UNITS + THREADS - 1) / THREADS;
-    static constexpr int NCH = TR ? 4 * NU : (CHUNKS + THREADS - 1) / THREADS;
-    static constexpr int NCOL = TR ? NU : NCH;   // distinct columns among a thread's chunks (K-table loaders)
+#ifdef MC_TR_UNITS   // first form (measured, slower): a thread gathers a 4 k x 4 x unit and writes four transposed 16-byte records
+    static constexpr bool TRU = TR;
+#else                // second form: the chunks and their threads stay as they are; a chunk (one k, four x) is written as four 4-byte stores
+    static constexpr bool TRU = false;
+#endif
+    static constexpr int NCH = TRU ? 4 * NU : (CHUNKS + THREADS - 1) / THREADS;
+    static constexpr int NCOL = TRU ? NU : NCH;   // distinct columns among a thread's chunks (K-table loaders)
     // (the chunk registers r[NCH] belong to the caller: a producer thread that serves ONE operand keeps one set for whichever it is)
 
     // register `it` of thread tid -> (k offset, x offset) of its chunk inside the tile, and whether the chunk exists
     __device__ static __forceinline__ void pos(int it, int tid, int& dk, int& dx, bool& live) {
-        if (TR) {
+        if (TRU) {
             const int u = tid + (it >> 2) * THREADS;
             live = UNITS % THREADS == 0 || u < UNITS;
             dk = (u / (ROWS / 4)) * 4 + (it & 3);
@@ -468,7 +473,7 @@ struct Loader {
             for (int ic = 0; ic < NCOL; ++ic) {
                 int dk, dx;
                 bool live;
-                pos(TR ? 4 * ic : ic, tid, dk, dx, live);
+                pos(TRU ? 4 * ic : ic, tid, dk, dx, live);
                 const int x = x0 + dx;
                 KCol col = ADDR::ktab_col(p, cg, g, x);
                 if (!((x < xlim) & live)) col.cy = KCOL_DEAD;
@@ -510,7 +515,7 @@ struct Loader {
                     const int2 e = ent[it];
                     const int dy = (int)(short)(e.y & 0xFFFF), dxx = e.y >> 16;
                     if (VEC == 4) {   // the column part was decoded once per tile (prep_cols)
-                        const KCol& cl = cols[TR ? it >> 2 : it];
+                        const KCol& cl = cols[TRU ? it >> 2 : it];
                         const bool ok = ((unsigned)(cl.cy + dy) < limY) & ((unsigned)(cl.cx + dxx) < limX) & (k < kend);
                         unsigned off = (unsigned)(cl.base + e.x) * 4u;
                         off = ok ? off : OOB;
@@ -614,7 +619,25 @@ struct Loader {
         return;
 #endif
         float4* l4 = reinterpret_cast<float4*>(lds);
-        if constexpr (TR) {
+        if constexpr (TR && !TRU) {
+            // chunk (k, x .. x+3) -> component k & 3 of the records of rows x .. x+3 of k-quad k >> 2: four ds_write_b32 a quarter
+            // pitch apart (immediate offsets); no register is regrouped, the threads and their loads are those of the plain form
+#pragma unroll
+            for (int it = 0; it < NCH; ++it) {
+                int dk, dx;
+                bool live;
+                pos(it, tid, dk, dx, live);
+                if (live) {
+                    float* q = lds + (((dk >> 2) * 4 * QP + (dx >> 2)) << 2) + (dk & 3);
+                    q[0] = r[it].x;
+                    q[4 * QP] = r[it].y;
+                    q[8 * QP] = r[it].z;
+                    q[12 * QP] = r[it].w;
+                }
+            }
+            return;
+        }
+        if constexpr (TRU) {
 #pragma unroll
             for (int iu = 0; iu < NU; ++iu) {
                 int dk, dx;
@@ -782,7 +805,7 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         // compile-time property of the producer instance (ROLE 1 = A, 2 = B, 0 = both), chosen once, outside the K loop: as a
         // branch inside it the compiler lost its exact vmcnt bookkeeping and drained the loads in flight every third step.
         constexpr int TA = (LA::UNITS + 63) / 64 * 64;
-        constexpr bool SPLIT = LA::TRANSPOSED && LB::TRANSPOSED && LA::NU == 1 && LB::NU == 1 && TA + LB::UNITS <= THREADS;
+        constexpr bool SPLIT = LA::TRU && LB::TRU && LA::NU == 1 && LB::NU == 1 && TA + LB::UNITS <= THREADS;
         auto produce = [&](auto persist_, auto tab_, auto role_) {
         constexpr bool PERSIST = decltype(persist_)::value;
         constexpr bool TAB = decltype(tab_)::value;   // the B loader reads the k part of its addresses from the LDS table

@@ -1,6 +1,10 @@
 set -u
-timeout -k 10 1000 python3 -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/pytest_full.log 2>&1; rc=$?
-tail -4 gpurun_out/pytest_full.log
-[ $rc -eq 0 ] || { grep -n "Error\|FAILED\|assert" gpurun_out/pytest_full.log | tail -20; exit 1; }
-timeout -k 10 120 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout -k 10 200 python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline 2>&1 | cut -c1-200
+MC_KERNELS_LIB=tools/variants/libmck_tr2.so timeout -k 10 300 python3 -u -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "conv_triplet or gemm or tile_choice" --timeout 200 --timeout-method thread 2>&1 | tail -4
+for rep in 1 2; do
+for lib in "" tools/variants/libmck_tr2.so; do
+  echo "== ${lib:-default} rep $rep"
+  for o in f b; do
+    MC_KERNELS_LIB=$lib MC_CONV_BAND=0 timeout -k 10 200 python3 tools/tile_sweep.py $o 2>&1 | grep -v "amdgpu.ids\|cccp5\|cccp6" || exit 1
+  done
+done
+done
