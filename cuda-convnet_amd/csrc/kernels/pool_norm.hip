@@ -49,6 +49,11 @@ __device__ __forceinline__ float4 vposmask(float4 y, float4 v) {
     return make_float4(y.x > 0.f ? v.x : 0.f, y.y > 0.f ? v.y : 0.f, y.z > 0.f ? v.z : 0.f, y.w > 0.f ? v.w : 0.f);
 }
 __device__ __forceinline__ float vposmask(float y, float v) { return y > 0.f ? v : 0.f; }
+// a relu's own backward step, in the reference's arithmetic: g * (y > 0) (ReluGradientOperator, neuron.cuh:173-178)
+__device__ __forceinline__ float4 vrelugrad(float4 y, float4 g) {
+    return make_float4(g.x * (y.x > 0.f), g.y * (y.y > 0.f), g.z * (y.z > 0.f), g.w * (y.w > 0.f));
+}
+__device__ __forceinline__ float vrelugrad(float y, float g) { return g * (y > 0.f); }
 __device__ __forceinline__ float4 vfma_s(float s, float4 a, float4 c) { return make_float4(s * a.x + c.x, s * a.y + c.y, s * a.z + c.z, s * a.w + c.w); }
 __device__ __forceinline__ float vfma_s(float s, float a, float c) { return s * a + c; }
 // a^e for a > 0 as exp2(e * log2 a) on the hardware transcendental units -- what the reference's __powf compiles to
@@ -130,7 +135,7 @@ __device__ __forceinline__ float kept(float g, const unsigned char* keep, size_t
 template <int V, bool RELU>
 __global__ void k_max_undo(const float* __restrict__ imgs, const float* __restrict__ maxGrads,
                            const float* __restrict__ maxActs, float* target, int N, int C, int imgSize, int subsX,
-                           int startX, int strideX, int outputsX, float sT, float sO, const unsigned char* __restrict__ keep) {
+                           int startX, int strideX, int outputsX, float sT, float sO, const unsigned char* __restrict__ keep, int gate) {
     typedef Vec<V> VV;
     const int nChunks = N / V;
     const int imgPix = imgSize * imgSize, numOut = outputsX * outputsX;
@@ -150,7 +155,10 @@ __global__ void k_max_undo(const float* __restrict__ imgs, const float* __restri
             for (int my = ylo; my < yhi; ++my)
                 for (int mx = xlo; mx < xhi; ++mx) {
                     const size_t o = ((size_t)c * numOut + my * outputsX + mx) * N + n;
-                    prod = vadd(prod, veqmul(img, VV::ld(maxActs + o), kept(VV::ld(maxGrads + o), keep, o)));
+                    const typename VV::T ma = VV::ld(maxActs + o);
+                    typename VV::T gv = kept(VV::ld(maxGrads + o), keep, o);
+                    if (gate) gv = vrelugrad(ma, gv);   // a relu sits on the pooled tensor (applied in place): its gradient step, fused
+                    prod = vadd(prod, veqmul(img, ma, gv));
                 }
             if (RELU) prod = vposmask(img, prod);   // the pooled images are a relu's output: its gradient mask, fused
         }
@@ -169,6 +177,7 @@ struct Map2D {
     int xBlocks;   // workgroups along x
     int band;      // rows per thread
     int xcd;       // workgroups of the launch / 8 when the XCD-aware order below is on, else 0
+    int relu;      // k_pool_fix: a relu on the pooled value, applied in the store
 };
 // Workgroups are dealt round-robin over the 8 XCDs in launch order (x fastest), each XCD with an L2 of its own.  The bands of one
 // channel overlap (a 3x3 / 2 window row is read by two bands, a max-undo block row reads the window rows of its neighbours), so in
@@ -263,7 +272,8 @@ __global__ void __launch_bounds__(256) k_pool_fix(const float* __restrict__ imgs
                 }
             if (!MAX) acc = vdivs(acc, (float)((y1 - y0) * (x1 - x0)));
             const size_t flat = (size_t)c * numOut * N + (size_t)(oy * outputsX + ox) * N + n;
-            VV::st(target + flat, acc);
+            if (!(mp.relu && dp.out == target)) VV::st(target + flat, acc);
+            if (mp.relu) VV::st(dp.out + flat, vmax(acc, VV::splat(0.f)));   // the relu above the pool: its output (in place when dp.out == target)
             if constexpr (DROP) {
                 unsigned bits;
                 VV::st(dp.out + flat, drop4(acc, dp, flat, bits));
@@ -295,7 +305,7 @@ template <bool RELU>
 __global__ void __launch_bounds__(256) k_max_undo_2d(const float* __restrict__ imgs, const float* __restrict__ maxGrads,
                                                      const float* __restrict__ maxActs, float* target, int N, int imgSize, int subsX,
                                                      int startX, int strideX, int outputsX, float sT, float sO, Map2D mp,
-                                                     const unsigned char* __restrict__ keep) {
+                                                     const unsigned char* __restrict__ keep, int gate) {
     typedef Vec<4> VV;
     const int LX = 1 << mp.lxShift;
     const int nl = threadIdx.x & (LX - 1), xl = threadIdx.x >> mp.lxShift;
@@ -322,7 +332,10 @@ __global__ void __launch_bounds__(256) k_max_undo_2d(const float* __restrict__ i
                 for (int my = ylo; my < yhi; ++my)
                     for (int mx = xlo; mx < xhi; ++mx) {
                         const size_t o = obase + (size_t)(my * outputsX + mx) * N + n;
-                        prod = vadd(prod, veqmul(img, VV::ld(maxActs + o), kept(VV::ld(maxGrads + o), keep, o)));
+                        const float4 ma = VV::ld(maxActs + o);
+                        float4 gv = kept(VV::ld(maxGrads + o), keep, o);
+                        if (gate) gv = vrelugrad(ma, gv);
+                        prod = vadd(prod, veqmul(img, ma, gv));
                     }
                 if (RELU) prod = vposmask(img, prod);
             }
@@ -338,7 +351,7 @@ template <bool RELU>
 __global__ void __launch_bounds__(256) k_max_undo_s2(const float* __restrict__ imgs, const float* __restrict__ maxGrads,
                                                      const float* __restrict__ maxActs, float* target, int N, int imgSize, int subsX,
                                                      int startX, int outputsX, float sT, float sO, Map2D mp,
-                                                     const unsigned char* __restrict__ keep) {
+                                                     const unsigned char* __restrict__ keep, int gate) {
     typedef Vec<4> VV;
     const int LX = 1 << mp.lxShift;
     const int nl = threadIdx.x & (LX - 1), xl = threadIdx.x >> mp.lxShift;
@@ -384,6 +397,7 @@ __global__ void __launch_bounds__(256) k_max_undo_s2(const float* __restrict__ i
                     const size_t o = obase + (ok ? (size_t)((ylo + ky) * outputsX + xlo + kx) * N : (size_t)0) + n;
                     a[ky][kx] = VV::ld(maxActs + o);
                     g[ky][kx] = kept(VV::ld(maxGrads + o), keep, o);
+                    if (gate) g[ky][kx] = vrelugrad(a[ky][kx], g[ky][kx]);
                     if (!ok) g[ky][kx] = z;
                 }
 #pragma unroll
@@ -424,6 +438,7 @@ inline Map2D make_map2d(int N, int rows, int cols, int C, dim3& grid) {
     static const bool noXcd = getenv("MC_POOL_NO_XCD_ORDER") != nullptr;   // A/B switch
     const long total = (long)grid.x * grid.y;
     mp.xcd = (!noXcd && total % 8 == 0 && total < (1L << 30)) ? (int)(total / 8) : 0;
+    mp.relu = 0;
     return mp;
 }
 
@@ -797,7 +812,7 @@ int mc_conv_local_pool(const float* images, float* target, int numImages, int nu
 
 static int max_undo_entry(const char* who, bool relu, const float* images, const float* maxGrads, const float* maxActs, float* target,
                           int numImages, int numFilters, int imgSize, int subsX, int startX, int strideX, int outputsX,
-                          float scaleTargets, float scaleOutput, mcStream_t s, const unsigned char* keep = nullptr) {
+                          float scaleTargets, float scaleOutput, mcStream_t s, const unsigned char* keep = nullptr, int gate = 0) {
     MC_REQUIRE(images && maxGrads && maxActs && target, "%s: null pointer", who);
     MC_REQUIRE(numImages > 0 && numFilters > 0 && imgSize > 0 && subsX > 0 && strideX > 0 && outputsX > 0, "%s: non-positive dimension", who);
     MC_REQUIRE((size_t)numFilters * imgSize * imgSize * numImages < (1ull << 31), "%s: tensor exceeds 32-bit indexing", who);
@@ -809,20 +824,20 @@ static int max_undo_entry(const char* who, bool relu, const float* images, const
     if (v && numFilters <= 65535 && strideX == 2 && s2fits && !nos2) {
         dim3 g2;
         const Map2D mp = make_map2d(numImages, (imgSize + 1) / 2, (imgSize + 1) / 2, numFilters, g2);
-        if (relu) hipLaunchKernelGGL(k_max_undo_s2<true>, g2, dim3(256), 0, S(s), images, maxGrads, maxActs, target, numImages, imgSize, subsX, startX, outputsX, scaleTargets, scaleOutput, mp, keep);
-        else hipLaunchKernelGGL(k_max_undo_s2<false>, g2, dim3(256), 0, S(s), images, maxGrads, maxActs, target, numImages, imgSize, subsX, startX, outputsX, scaleTargets, scaleOutput, mp, keep);
+        if (relu) hipLaunchKernelGGL(k_max_undo_s2<true>, g2, dim3(256), 0, S(s), images, maxGrads, maxActs, target, numImages, imgSize, subsX, startX, outputsX, scaleTargets, scaleOutput, mp, keep, gate);
+        else hipLaunchKernelGGL(k_max_undo_s2<false>, g2, dim3(256), 0, S(s), images, maxGrads, maxActs, target, numImages, imgSize, subsX, startX, outputsX, scaleTargets, scaleOutput, mp, keep, gate);
         return launch_status(who);
     }
     if (v && numFilters <= 65535) {
         dim3 g2;
         const Map2D mp = make_map2d(numImages, imgSize, imgSize, numFilters, g2);
-        if (relu) hipLaunchKernelGGL(k_max_undo_2d<true>, g2, dim3(256), 0, S(s), images, maxGrads, maxActs, target, numImages, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput, mp, keep);
-        else hipLaunchKernelGGL(k_max_undo_2d<false>, g2, dim3(256), 0, S(s), images, maxGrads, maxActs, target, numImages, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput, mp, keep);
+        if (relu) hipLaunchKernelGGL(k_max_undo_2d<true>, g2, dim3(256), 0, S(s), images, maxGrads, maxActs, target, numImages, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput, mp, keep, gate);
+        else hipLaunchKernelGGL(k_max_undo_2d<false>, g2, dim3(256), 0, S(s), images, maxGrads, maxActs, target, numImages, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput, mp, keep, gate);
         return launch_status(who);
     }
     const size_t items = (size_t)numFilters * imgSize * imgSize * (numImages / (v ? 4 : 1));
     dim3 g(grid_items(items)), b(TPB);
-#define MC_MU(V, R) hipLaunchKernelGGL((k_max_undo<V, R>), g, b, 0, S(s), images, maxGrads, maxActs, target, numImages, numFilters, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput, keep)
+#define MC_MU(V, R) hipLaunchKernelGGL((k_max_undo<V, R>), g, b, 0, S(s), images, maxGrads, maxActs, target, numImages, numFilters, imgSize, subsX, startX, strideX, outputsX, scaleTargets, scaleOutput, keep, gate)
     if (v && relu) MC_MU(4, true);
     else if (v) MC_MU(4, false);
     else if (relu) MC_MU(1, true);
@@ -851,6 +866,34 @@ int mc_conv_local_max_undo_dropout(const float* images, const float* maxGrads, c
     MC_REQUIRE(keep, "mc_conv_local_max_undo_dropout: null keep bytes");
     return max_undo_entry("mc_conv_local_max_undo_dropout", reluGrad != 0, images, maxGrads, maxActs, target, numImages, numFilters, imgSize,
                           subsX, startX, strideX, outputsX, scaleTargets, scaleOutput, s, keep);
+}
+
+int mc_conv_local_max_undo_relu_out(const float* images, const float* maxGrads, const float* maxActs, float* target, int numImages,
+                                    int numFilters, int imgSize, int subsX, int startX, int strideX, int outputsX, float scaleTargets,
+                                    float scaleOutput, int reluGrad, mcStream_t s) {
+    return max_undo_entry("mc_conv_local_max_undo_relu_out", reluGrad != 0, images, maxGrads, maxActs, target, numImages, numFilters, imgSize,
+                          subsX, startX, strideX, outputsX, scaleTargets, scaleOutput, s, nullptr, 1);
+}
+
+int mc_conv_local_pool_relu(const float* images, float* target, float* reluTarget, int numImages, int numFilters, int imgSize, int subsX,
+                            int startX, int strideX, int outputsX, int pooler, mcStream_t s) {
+    MC_REQUIRE(images && target && reluTarget, "mc_conv_local_pool_relu: null pointer");
+    MC_POOLARGS_OK("mc_conv_local_pool_relu");
+    MC_REQUIRE(pooler == MC_POOL_MAX || pooler == MC_POOL_AVG, "mc_conv_local_pool_relu: unknown pooler %d", pooler);
+    if (use_vec(numImages, {images, target, reluTarget}) && numFilters <= 65535 && (subsX == 2 || subsX == 3)) {
+        dim3 g2;
+        Map2D mp = make_map2d(numImages, outputsX, outputsX, numFilters, g2);
+        mp.relu = 1;
+        const DropArgs dp{reluTarget, nullptr, 0.f, 0, 0};
+#define MC_PFR(MAXP, SZ) hipLaunchKernelGGL((k_pool_fix<MAXP, SZ>), g2, dim3(256), 0, S(s), images, target, numImages, imgSize, startX, strideX, outputsX, mp, dp)
+        if (pooler == MC_POOL_MAX) { if (subsX == 2) MC_PFR(true, 2); else MC_PFR(true, 3); }
+        else { if (subsX == 2) MC_PFR(false, 2); else MC_PFR(false, 3); }
+#undef MC_PFR
+        return launch_status("mc_conv_local_pool_relu");
+    }
+    const int rc = mc_conv_local_pool(images, target, numImages, numFilters, imgSize, subsX, startX, strideX, outputsX, pooler, s);
+    if (rc) return rc;
+    return mc_neuron_activate(MC_N_RELU, 0.f, 0.f, target, reluTarget, (size_t)numFilters * outputsX * outputsX * numImages, s);
 }
 
 size_t mc_dropout_keep_bytes(size_t n) { return (n + 3) / 4; }

@@ -204,8 +204,8 @@ NeuronLayer::NeuronLayer(ConvNet* convNet, PyObject* paramsDict) : Layer(convNet
 
 void NeuronLayer::fpropActs(int, float, PASS_TYPE passType) {
     if (_fused) return;   // the producing contraction already applied relu in its epilogue, in place
-    if (_dropFwd) {       // the pool layer below wrote this layer's output in its own store (fuseDropoutIntoPool)
-        _dropFwd = false;
+    if (_dropFwd || _reluFwd) {   // the pool layer below wrote this layer's output in its own store (fuseDropoutIntoPool / fuseReluIntoPool)
+        _dropFwd = _reluFwd = false;
         return;
     }
     _neuron->activate(*_inputs[0], getActs(), passType);
@@ -221,6 +221,16 @@ bool NeuronLayer::fuseDropoutIntoPool(size_t numel, PASS_TYPE passType, float* p
     // backward: only when this layer hands the gradient down in place (the pool then reads the very matrix the layer above
     // wrote) and has a single gradient producer (nothing accumulates into it)
     _dropBwd = _actsGradTarget == 0 && _numGradProducersNext == 1;
+    return true;
+}
+
+bool NeuronLayer::fuseReluIntoPool(PASS_TYPE passType) {
+    static const bool off = getenv("MC_NO_FUSE_POOL_RELU") != nullptr;
+    _reluBwd = false;
+    if (off || !_neuron->isRelu() || _prev.size() != 1 || _actsTarget > 0) return false;   // in place (_actsTarget == 0) or a matrix of its own
+    _reluFwd = true;
+    _bitsValid = false;
+    _reluBwd = passType != PASS_TEST && _actsGradTarget == 0 && _numGradProducersNext == 1;
     return true;
 }
 
@@ -258,6 +268,11 @@ const unsigned* Layer::claimReluGradBits(int inpIdx) {
 void NeuronLayer::bpropActs(DevMat& v, int, float scaleTargets, PASS_TYPE passType) {
     if (_dropBwd && _neuron->fusedDropoutActive() && passType == PASS_TRAIN && scaleTargets == 0.f) return;   // the pool's max-undo applies the keep bytes
     _dropBwd = false;
+    if (_reluBwd && scaleTargets == 0.f) {   // the pool's max-undo gates the gradient by its relu'd output
+        _gradMasked = false;
+        return;
+    }
+    _reluBwd = false;
     if (_gradMasked) {   // the layer above stored grad * (act > 0) straight into the shared gradient matrix
         _gradMasked = false;
         return;
@@ -967,11 +982,25 @@ void MaxPoolLayer::fpropActs(int, float, PASS_TYPE passType) {
         _dropNext = nl;
         return;
     }
+    // layers-80sec / 18pct: `neuron=relu` on the pool layer, an in-place relu above: applied in this layer's store
+    _reluNext = nullptr;
+    if (nl && nl->fuseReluIntoPool(passType)) {
+        if (!nl->inPlace()) nl->getActs().resize(getActs());
+        RT_MC(mc_conv_local_pool_relu(_inputs[0]->data(), getActs().data(), nl->getActs().data(), numCases(), _channels, _imgSize, _sizeX, _start, _stride, _outputsX, MC_POOL_MAX, ST()));
+        _reluNext = nl;
+        return;
+    }
     RT_MC(mc_conv_local_pool(_inputs[0]->data(), getActs().data(), numCases(), _channels, _imgSize, _sizeX, _start, _stride, _outputsX, MC_POOL_MAX, ST()));
 }
 
 void MaxPoolLayer::bpropActs(DevMat& v, int, float scaleTargets, PASS_TYPE passType) {
     const float* mask = scaleTargets == 0.f ? claimReluGradMask(0) : nullptr;   // == _prev[0]->getActs()
+    if (_reluNext && _reluNext->poolGatesRelu()) {   // v has not passed the relu's backward step yet: gated here
+        RT_MC(mc_conv_local_max_undo_relu_out(mask ? mask : _prev[0]->getActs().data(), v.data(), getActs().data(), _prev[0]->getActsGrad().data(),
+                                              numCases(), _channels, _imgSize, _sizeX, _start, _stride, _outputsX, mask ? 0.f : scaleTargets, 1.f,
+                                              mask ? 1 : 0, ST()));
+        return;
+    }
     if (_dropNext && _dropNext->poolUndoesDropout() && passType == PASS_TRAIN) {   // v has not passed the dropout's backward step yet: masked here
         RT_MC(mc_conv_local_max_undo_dropout(mask ? mask : _prev[0]->getActs().data(), v.data(), getActs().data(), reinterpret_cast<const unsigned char*>(_keep.data()),
                                              _prev[0]->getActsGrad().data(), numCases(), _channels, _imgSize, _sizeX, _start, _stride, _outputsX,

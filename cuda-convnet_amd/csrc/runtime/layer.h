@@ -221,18 +221,24 @@ public:
     unsigned* bitsBuffer(int rows, int ld);
     void setBitsValid(bool v) { _bitsValid = v; }
     const unsigned* validBits() const { return _bitsValid ? reinterpret_cast<const unsigned*>(_bits.data()) : nullptr; }
-    void abortPass() override { Layer::abortPass(); _gradMasked = false; _bitsValid = false; _dropFwd = _dropBwd = false; }
+    void abortPass() override { Layer::abortPass(); _gradMasked = false; _bitsValid = false; _dropFwd = _dropBwd = false; _reluFwd = _reluBwd = false; }
     // Dropout fused into the pool layer below (MaxPoolLayer): the pool asks in its forward step; a yes means it writes this
     // layer's output itself (this layer's own forward step is then skipped) and, when the gradient side allows it -- this layer
     // hands its gradient down in place and nothing accumulates -- also masks the gradient in its max-undo (backward step skipped).
     bool fuseDropoutIntoPool(size_t numel, PASS_TYPE passType, float* prob, unsigned long long* seed, unsigned long long* offset);
     bool poolUndoesDropout() const { return _dropBwd; }
+    // An in-place relu on a max-pool layer (`neuron=relu` in the pool's definition): the pool applies it in its own store
+    // (setFusedIntoProducer) and, when this layer hands its gradient down in place and nothing accumulates into it, also takes over
+    // the relu's backward step in its max-undo (the gradient gated by the relu'd pooled value it routes by anyway).
+    bool fuseReluIntoPool(PASS_TYPE passType);
+    bool poolGatesRelu() const { return _reluBwd; }
 
 protected:
     void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
     void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
     Neuron* _neuron;
     bool _dropFwd = false, _dropBwd = false;
+    bool _reluFwd = false, _reluBwd = false;   // this pass: the pool below wrote this relu's output / applies its backward step
     bool _fused = false;
     bool _gradMasked = false;   // this pass's gradient already carries the relu mask (see claimReluGradMask)
     bool _bitsValid = false;
@@ -457,12 +463,13 @@ protected:
 class MaxPoolLayer : public PoolLayer {
 public:
     MaxPoolLayer(ConvNet* convNet, PyObject* paramsDict) : PoolLayer(convNet, paramsDict) {}
-    void abortPass() override { PoolLayer::abortPass(); _dropNext = nullptr; }
+    void abortPass() override { PoolLayer::abortPass(); _dropNext = nullptr; _reluNext = nullptr; }
 
 protected:
     void fpropActs(int inpIdx, float scaleTargets, PASS_TYPE passType) override;
     void bpropActs(DevMat& v, int inpIdx, float scaleTargets, PASS_TYPE passType) override;
     NeuronLayer* _dropNext = nullptr;   // this pass: the dropout layer above whose forward step ran inside this layer's
+    NeuronLayer* _reluNext = nullptr;   // this pass: the in-place relu above, applied in this layer's store
     DevMat _keep;                       // its keep bytes (one per four elements), held in a float matrix
 };
 

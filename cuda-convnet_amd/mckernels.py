@@ -46,6 +46,8 @@ _SIGS = {
     "mc_conv_local_max_undo_relu_grad": [c_fp] * 4 + [c_i] * 7 + [c_f, c_f, c_fp],
     "mc_conv_local_pool": [c_fp, c_fp] + [c_i] * 8 + [c_fp],
     "mc_conv_local_max_undo": [c_fp] * 4 + [c_i] * 7 + [c_f, c_f, c_fp],
+    "mc_conv_local_pool_relu": [c_fp, c_fp, c_fp] + [c_i] * 8 + [c_fp],
+    "mc_conv_local_max_undo_relu_out": [c_fp] * 4 + [c_i] * 7 + [c_f, c_f, c_i, c_fp],
     "mc_conv_local_pool_dropout": [c_fp] * 4 + [c_i] * 8 + [c_f, c_u64, c_u64, c_fp],
     "mc_conv_local_max_undo_dropout": [c_fp] * 5 + [c_i] * 7 + [c_f, c_f, c_i, c_fp],
     "mc_conv_local_avg_undo": [c_fp] * 2 + [c_i] * 7 + [c_f, c_f, c_fp],

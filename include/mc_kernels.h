@@ -235,6 +235,22 @@ int mc_conv_local_max_undo_relu_grad(const float* images, const float* maxGrads,
                                      float* target, int numImages, int numFilters, int imgSize,
                                      int subsX, int startX, int strideX, int outputsX,
                                      float scaleTargets, float scaleOutput, mcStream_t stream);
+/* convLocalPool (Kernel/include/conv/conv_util.cuh:335-524) followed by the relu neuron that `neuron=relu` puts on a pool layer
+ * (NeuronLayer::fpropActs, Kernel/src/layers/layer.cu:260-262; ReluNeuron, Kernel/include/layers/neuron.cuh:152-181), applied in
+ * place or into its own matrix: target = pool(images), reluTarget = max(0, target), one pass (reluTarget == target: in place; max
+ * pools keep the pooled tensor for their backward pass, so the reference's parser gives the neuron a matrix of its own).
+ * Bit-identical to mc_conv_local_pool + mc_neuron_activate(MC_N_RELU) on the result. */
+int mc_conv_local_pool_relu(const float* images, float* target, float* reluTarget, int numImages, int numFilters, int imgSize, int subsX,
+                            int startX, int strideX, int outputsX, int pooler, mcStream_t stream);
+/* convLocalMaxUndo (Kernel/src/conv/conv_util.cu:1502-1572, 1868-1900) for a pool whose output carries that in-place relu: maxActs is
+ * the pooled tensor (relu'd or not: the two agree on which entries are positive), maxGrads the gradient with respect to it BEFORE the relu's own backward step (NeuronLayer::bpropActs,
+ * layer.cu:256-258; ReluGradientOperator, neuron.cuh:173-181), which is applied here
+ * to every window's gradient (maxActs > 0 ? maxGrads : 0).  reluGrad != 0 also applies the relu gradient of the layer below, as
+ * mc_conv_local_max_undo_relu_grad does.  Bit-identical to mc_neuron_input_grad(MC_N_RELU) + the plain undo. */
+int mc_conv_local_max_undo_relu_out(const float* images, const float* maxGrads, const float* maxActs, float* target, int numImages,
+                                    int numFilters, int imgSize, int subsX, int startX, int strideX, int outputsX, float scaleTargets,
+                                    float scaleOutput, int reluGrad, mcStream_t stream);
+
 /* convLocalPool followed by the plugin's dropout neuron (PluginsSrc/include/extralayers.cuh:39-77, train mode: u < prob ? 0 : x,
  * no rescale) in ONE pass over the pooled tensor: `target` gets the pooled values (convLocalMaxUndo routes by them,
  * conv_util.cu:1567), `dropTarget` (another buffer) what mc_dropout_counter(target, dropTarget, prob, 0, n, seed, offset) would

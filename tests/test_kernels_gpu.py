@@ -395,6 +395,46 @@ def test_pool_with_fused_dropout(N, C, S, size, start, stride):
             assert np.array_equal(host(a), host(b)), (relu, sT)
 
 
+@pytest.mark.parametrize("N,C,S,size,start,stride", [(128, 32, 32, 3, 0, 2), (128, 16, 8, 2, 1, 2), (16, 8, 9, 4, -1, 2), (6, 16, 6, 4, -2, 4),
+                                                     (5, 3, 7, 3, 0, 2), (12, 8, 9, 3, 0, 2)])
+def test_pool_with_fused_relu(N, C, S, size, start, stride):
+    """`neuron=relu` on a max-pool layer (layers-80sec pool1) as one forward and one backward pass: mc_conv_local_pool_relu stores
+    max(0, pooled); mc_conv_local_max_undo_relu_out applies the relu's backward step to every window's gradient as it routes it.
+    Bit-identical to the separate kernels (pool, relu in place, relu gradient, max-undo with and without the relu gradient of the
+    layer below, plain and accumulating) on the fast paths, the general path, and image counts that are not a multiple of 4."""
+    m = mc()
+    rng = np.random.default_rng(62)
+    outX = int(np.ceil((S - start - size) / float(stride))) + 1
+    n = C * outX * outX * N
+    x = rng.standard_normal((C * S * S, N)).astype(np.float32) - 0.8     # many windows whose maximum is negative
+    x[rng.random(x.shape) < 0.2] = 0.0                                   # and exact zeros, which tie with a relu'd maximum of 0
+    dx = dev(x)
+    for pooler in (m.POOL_MAX, m.POOL_AVG):
+        y0, y1 = nans(C * outX * outX, N), nans(C * outX * outX, N)
+        m.call("mc_conv_local_pool", ptr(dx), ptr(y0), N, C, S, size, start, stride, outX, pooler, None)
+        r0, r1 = nans(C * outX * outX, N), nans(C * outX * outX, N)
+        m.call("mc_neuron_activate", 1, 0.0, 0.0, ptr(y0), ptr(r0), n, None)
+        m.call("mc_conv_local_pool_relu", ptr(dx), ptr(y1), ptr(r1), N, C, S, size, start, stride, outX, pooler, None)     # a matrix of its own
+        assert np.array_equal(host(y0), host(y1)) and np.array_equal(host(r0), host(r1)), pooler
+        m.call("mc_conv_local_pool_relu", ptr(dx), ptr(y1), ptr(y1), N, C, S, size, start, stride, outX, pooler, None)     # in place
+        assert np.array_equal(host(r0), host(y1)), pooler
+        if pooler == m.POOL_MAX:
+            ymax = y1
+    assert (host(ymax) == 0).mean() > 0.05
+    g = dev(rng.standard_normal((C * outX * outX, N)))
+    gr = nans(C * outX * outX, N)
+    m.call("mc_neuron_input_grad", 1, 0.0, 0.0, ptr(g), ptr(ymax), ptr(gr), 0, n, None)
+    prev = rng.standard_normal(x.shape).astype(np.float32)
+    for relu in (0, 1):
+        for sT in ((0.0,) if relu else (0.0, 1.0)):
+            a = nans(*x.shape) if sT == 0 else dev(prev)
+            b = nans(*x.shape) if sT == 0 else dev(prev)
+            m.call("mc_conv_local_max_undo_relu_grad" if relu else "mc_conv_local_max_undo", ptr(dx), ptr(gr), ptr(ymax), ptr(a), N, C, S, size, start,
+                   stride, outX, sT, 1.0, None)
+            m.call("mc_conv_local_max_undo_relu_out", ptr(dx), ptr(g), ptr(ymax), ptr(b), N, C, S, size, start, stride, outX, sT, 1.0, relu, None)
+            assert np.array_equal(host(a), host(b)), (relu, sT)
+
+
 def test_bias_and_reductions():
     m = mc()
     rng = np.random.default_rng(20)

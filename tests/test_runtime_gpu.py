@@ -411,6 +411,18 @@ def test_dropout_fused_into_the_pools_changes_no_bit(net_name, cases, mini):
             np.testing.assert_array_equal(a[k], b[k], err_msg=k)
 
 
+@pytest.mark.parametrize("net_name,cases,mini", [("80sec", 4 * 32 + 12, 32), ("18pct", 3 * 16, 16)])
+def test_relu_fused_into_the_pool_changes_no_bit(net_name, cases, mini):
+    """layers-80sec / 18pct put `neuron=relu` on pool1: the max-pool layer applies it in its own store and the relu's backward step in
+    its max-undo (NeuronLayer::fuseReluIntoPool, mc_conv_local_pool_relu / mc_conv_local_max_undo_relu_out).  Everything the batch
+    leaves behind equals a run with the separate kernels (MC_NO_FUSE_POOL_RELU=1) bit for bit."""
+    a, _ = run_child(net=net_name, cases=cases, mini=mini)
+    b, _ = run_child(net=net_name, cases=cases, mini=mini, _env={"MC_NO_FUSE_POOL_RELU": "1"})
+    for k in a:
+        if k.startswith(("W:", "B:", "Winc:", "Binc:", "cost:")):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
 @pytest.mark.parametrize("net_name,cases,mini", [("nin-tiny", 128, 64), ("nin-tiny", 6 * 32, 32), ("conv-local", 5 * 16, 16)])
 def test_single_rank_rccl_path_is_identity(net_name, cases, mini):
     """world_size 1 through the real RCCL all-reduce / side-stream / event path gives the same
