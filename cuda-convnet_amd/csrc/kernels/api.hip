@@ -298,6 +298,14 @@ int pick_gemm_chunks(int m, int n, int k, bool kc) {
             long want = num_cus();
             const long maxc = k / 256;
             if (want > maxc) want = maxc;
+            // Too short a k for three quarters of the CUs to get a whole-output workgroup each: 96 x 96 quarter tiles on a
+            // quarter of the CUs' worth of chunks instead (one round of workgroups, half the slabs to reduce).  Measured
+            // (tools/mf_probe.py, product + reduction + row sums): 192 x 192 x 32768 (NIN cccp3 / cccp4) 39.9 us as 96 x 192 halves
+            // of 128 chunks, 36.3 as quarters of 64; 192 x 192 x 8192 (cccp5) 20.3 -> 18.2.
+            if (4 * want < 3L * num_cus() && m > 96 && n > 96) {
+                want = num_cus() / 4;
+                if (want > k / 128) want = k / 128;
+            }
             return want < 1 ? 1 : (int)want;
         }
     }

@@ -728,7 +728,7 @@ def test_gemm_row_sums(m_, n_, k_):
     ref = nans(m_, n_)
     m.call("mc_gemm", ptr(dA), ptr(dB), ptr(ref), m_, n_, k_, 0, 1, k_, k_, n_, 0.0, 0.5, None, m.NEURON_NONE, ptr(ws), wsb, None)
     wsr = m.lib().mc_gemm_row_sums_workspace_bytes(m_, n_, k_)
-    assert (wsr == 0) == (wsb == 0) and wsr >= wsb
+    assert (wsr == 0) == (wsb == 0)      # (mc_gemm's figure covers either orientation's chunk plan, this one the weight-gradient plan + its sums)
     wsR = nans(max(1, wsr // 4))
     outs = []
     for _ in range(2):
