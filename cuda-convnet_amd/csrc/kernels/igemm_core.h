@@ -427,7 +427,7 @@ struct Loader {
     static constexpr bool LKC = KC || TR;   // LDS holds k-quads per row (read with b128 / b64), not [k][rows]
     static constexpr int ROWSP = ROWS + 1;
     static constexpr int QP = (ROWS / 4 + 3) / 8 * 8 + 4;   // the least QP >= ROWS / 4 with QP % 8 == 4
-    static constexpr int LDS_FLOATS = TR ? (BK / 4) * 4 * QP * 4 : KC ? (BK / 4) * ROWSP * 4 : BK * ROWS;
+    static constexpr int LDS_FLOATS_TR = (BK / 4) * 4 * QP * 4;   // (the pair form's footprint is set below, once HP is known)
     static constexpr int CHUNKS = BK * ROWS / 4;
     static constexpr int UNITS = (BK / 4) * (ROWS / 4);
     static constexpr int NU = (UNITS + THREADS - 1) / THREADS;
@@ -436,8 +436,23 @@ struct Loader {
 #else                // second form: the chunks and their threads stay as they are; a chunk (one k, four x) is written as four 4-byte stores
     static constexpr bool TRU = false;
 #endif
-    static constexpr int NCH = TRU ? 4 * NU : (CHUNKS + THREADS - 1) / THREADS;
-    static constexpr int NCOL = TRU ? NU : NCH;   // distinct columns among a thread's chunks (K-table loaders)
+#ifdef MC_TR_PAIR    // third form: a thread gathers 4 consecutive k x TWO consecutive x (four 8-byte loads: a wave's load is still one
+                     // contiguous 512-byte run of a k row) and writes two 16-byte records.  Register ring, threads and store count
+                     // are those of the plain form; twice the load instructions and address arithmetic.
+    static constexpr bool TRP = TR;
+#else
+    static constexpr bool TRP = false;
+#endif
+    static_assert(!(TRU && TRP), "one transposing form at a time");
+    // rows dealt over two halves of pitch HP records (even rows, odd rows): lane L of a wave writes rows 2L and 2L + 1 -> consecutive
+    // records in each half (8 contiguous lanes per ds_write_b128 group: no conflict); HP = 8 (mod 16) makes the consumers' 16-lane
+    // ds_read_b128 groups conflict-free: lane l31 reads record (l31 & 1) HP + (l31 >> 1) + const
+    static constexpr int HP = (ROWS / 2 + 7) / 16 * 16 + 8;
+    static constexpr int UP = (BK / 4) * (ROWS / 2);
+    static constexpr int NUP = (UP + THREADS - 1) / THREADS;
+    static constexpr int NCH = TRU ? 4 * NU : TRP ? 2 * NUP : (CHUNKS + THREADS - 1) / THREADS;
+    static constexpr int NCOL = TRU ? NU : TRP ? NUP : NCH;   // distinct columns among a thread's chunks (K-table loaders)
+    static constexpr int LDS_FLOATS = TRP ? (BK / 4) * 2 * HP * 4 : TR ? LDS_FLOATS_TR : KC ? (BK / 4) * ROWSP * 4 : BK * ROWS;
     // (the chunk registers r[NCH] belong to the caller: a producer thread that serves ONE operand keeps one set for whichever it is)
 
     // register `it` of thread tid -> (k offset, x offset) of its chunk inside the tile, and whether the chunk exists
@@ -447,6 +462,11 @@ struct Loader {
             live = UNITS % THREADS == 0 || u < UNITS;
             dk = (u / (ROWS / 4)) * 4 + (it & 3);
             dx = (u % (ROWS / 4)) * 4;
+        } else if (TRP) {   // it = 2 * unit: the unit's first k and its x pair
+            const int u = tid + (it >> 1) * THREADS;
+            live = UP % THREADS == 0 || u < UP;
+            dk = (u / (ROWS / 2)) * 4;
+            dx = (u % (ROWS / 2)) * 2;
         } else {
             const int c = tid + it * THREADS;
             live = CHUNKS % THREADS == 0 || c < CHUNKS;
@@ -473,7 +493,7 @@ struct Loader {
             for (int ic = 0; ic < NCOL; ++ic) {
                 int dk, dx;
                 bool live;
-                pos(TRU ? 4 * ic : ic, tid, dk, dx, live);
+                pos(TRU ? 4 * ic : TRP ? 2 * ic : ic, tid, dk, dx, live);
                 const int x = x0 + dx;
                 KCol col = ADDR::ktab_col(p, cg, g, x);
                 if (!((x < xlim) & live)) col.cy = KCOL_DEAD;
@@ -491,6 +511,43 @@ struct Loader {
 #ifdef MC_ABL_NOFETCH   // timing-only ablation builds (tools/build_variant.sh); wrong results
         if (k0 > 0) return;
 #endif
+        if constexpr (TRP) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int iu = 0; iu < NUP; ++iu) {
+                int dk, dx;
+                bool live;
+                pos(2 * iu, tid, dk, dx, live);
+                const int x = x0 + dx;
+                unsigned off[4];
+                if constexpr (has_ktab<ADDR>::value && TAB) {
+                    const unsigned limY = (unsigned)ADDR::ktab_limY(cg), limX = (unsigned)ADDR::ktab_limX(cg);
+                    int2 ent[4];
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub) ent[sub] = ktab[k0 + dk + sub];   // the table is padded to a whole K tile
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub) asm volatile("" : "+v"(ent[sub].x), "+v"(ent[sub].y));
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub) {
+                        const int dy = (int)(short)(ent[sub].y & 0xFFFF), dxx = ent[sub].y >> 16;
+                        const bool ok = ((unsigned)(cols[iu].cy + dy) < limY) & ((unsigned)(cols[iu].cx + dxx) < limX) & (k0 + dk + sub < kend);
+                        off[sub] = ok ? (unsigned)(cols[iu].base + ent[sub].x) * 4u : OOB;
+                    }
+                } else {
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub) {
+                        int o;
+                        const bool ok = ADDR::addr(p, cg, g, b, k0 + dk + sub, x, o) & (k0 + dk + sub < kend) & (x < xlim) & live;
+                        off[sub] = ok ? (unsigned)o * 4u : OOB;
+                    }
+                }
+                const u32x2 v0 = __builtin_amdgcn_raw_buffer_load_b64(rs, off[0], 0, 0), v1 = __builtin_amdgcn_raw_buffer_load_b64(rs, off[1], 0, 0);
+                const u32x2 v2 = __builtin_amdgcn_raw_buffer_load_b64(rs, off[2], 0, 0), v3 = __builtin_amdgcn_raw_buffer_load_b64(rs, off[3], 0, 0);
+                r[2 * iu] = make_float4(__uint_as_float(v0.x), __uint_as_float(v0.y), __uint_as_float(v1.x), __uint_as_float(v1.y));
+                r[2 * iu + 1] = make_float4(__uint_as_float(v2.x), __uint_as_float(v2.y), __uint_as_float(v3.x), __uint_as_float(v3.y));
+            }
+            return;
+        }
         if constexpr (has_ktab<ADDR>::value && TAB) {
             {   // the k part of the address comes from the table (see KCol)
                 const unsigned limY = (unsigned)ADDR::ktab_limY(cg), limX = (unsigned)ADDR::ktab_limX(cg);
@@ -619,6 +676,22 @@ struct Loader {
         return;
 #endif
         float4* l4 = reinterpret_cast<float4*>(lds);
+        if constexpr (TRP) {
+#pragma unroll
+            for (int iu = 0; iu < NUP; ++iu) {
+                int dk, dx;
+                bool live;
+                pos(2 * iu, tid, dk, dx, live);
+                float4 a = r[2 * iu], b = r[2 * iu + 1];   // (k0: x, x+1 | k1: x, x+1), (k2 | k3)
+                asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));   // regroup HERE, not behind the loads
+                if (live) {
+                    float4* q = l4 + (dk >> 2) * 2 * HP + (dx >> 1);
+                    q[0] = make_float4(a.x, a.z, b.x, b.z);
+                    q[HP] = make_float4(a.y, a.w, b.y, b.w);
+                }
+            }
+            return;
+        }
         if constexpr (TR && !TRU) {
             // chunk (k, x .. x+3) -> component k & 3 of the records of rows x .. x+3 of k-quad k >> 2: four ds_write_b32 a quarter
             // pitch apart (immediate offsets); no register is regrouped, the threads and their loads are those of the plain form
@@ -1109,7 +1182,9 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
             const int row = (wm * MT + a) * 32 + l31;
             if (LA::LKC) {
                 // float4 index of (k-quad, row): k-contiguous loaders [quad][ROWS + 1], transposing loaders quarters of pitch QP
-                const int qi = LA::KC ? (k8 * 2 + h) * LA::ROWSP + row : (k8 * 2 + h) * 4 * LA::QP + (l31 & 3) * LA::QP + (wm * MT + a) * 8 + (l31 >> 2);
+                const int qi = LA::KC ? (k8 * 2 + h) * LA::ROWSP + row
+                             : LA::TRP ? (k8 * 2 + h) * 2 * LA::HP + (l31 & 1) * LA::HP + (wm * MT + a) * 16 + (l31 >> 1)
+                                       : (k8 * 2 + h) * 4 * LA::QP + (l31 & 3) * LA::QP + (wm * MT + a) * 8 + (l31 >> 2);
                 if (MT >= 5 || KQ == 2) {   // tall / 3x3 wave tiles: two b64 reads per k8 group halve the fragment registers in flight
                     if ((e & 1) == 0) {
                         const float2 v = reinterpret_cast<const float2*>(cA)[qi * 2 + (e >> 1)];
@@ -1135,7 +1210,9 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         for (int b = 0; b < NT; ++b) {
             const int col = (wn * NT + b) * 32 + l31;
             if (LB::LKC) {
-                const int qi = LB::KC ? (k8 * 2 + h) * LB::ROWSP + col : (k8 * 2 + h) * 4 * LB::QP + (l31 & 3) * LB::QP + (wn * NT + b) * 8 + (l31 >> 2);
+                const int qi = LB::KC ? (k8 * 2 + h) * LB::ROWSP + col
+                             : LB::TRP ? (k8 * 2 + h) * 2 * LB::HP + (l31 & 1) * LB::HP + (wn * NT + b) * 16 + (l31 >> 1)
+                                       : (k8 * 2 + h) * 4 * LB::QP + (l31 & 3) * LB::QP + (wn * NT + b) * 8 + (l31 >> 2);
                 if (KQ == 2) {
                     if ((e & 1) == 0) {
                         const float2 v = reinterpret_cast<const float2*>(cB)[qi * 2 + (e >> 1)];
