@@ -869,7 +869,10 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         // The consumers were dispatched first, so at equal priority they win every vector-issue arbitration
         // and a SIMD with two MFMA waves leaves the producers ~1 issue slot per 30 cycles (measured with
         // MC_STAMP).  Producers are short bursts between long waits: give them the slot when they want it.
-        __builtin_amdgcn_s_setprio(3);
+#ifndef MC_PRODUCER_PRIO
+#define MC_PRODUCER_PRIO 3
+#endif
+        __builtin_amdgcn_s_setprio(MC_PRODUCER_PRIO);
 #endif
         const __amdgpu_buffer_rsrc_t ra = make_rsrc(AADDR::base(pa), pa.bytes), rb = make_rsrc(BADDR::base(pb), pb.bytes);
         // Register sets.  When both operands take the transposing loader and their units fit the 256 producer threads side by
