@@ -675,6 +675,11 @@ struct Loader {
 #ifdef MC_ABL_NOCOMMIT
         return;
 #endif
+#ifdef MC_ABL_NOWRITE   // timing-only ablation: the loads are waited for and their registers consumed, nothing is written to LDS
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) asm volatile("" ::"v"(r[it].x), "v"(r[it].y), "v"(r[it].z), "v"(r[it].w));
+        return;
+#endif
         float4* l4 = reinterpret_cast<float4*>(lds);
         if constexpr (TRP) {
 #pragma unroll
