@@ -421,6 +421,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsi
 template <class ADDR, int ROWS, int BK, int VEC, bool PERM = false, bool TR = false>
 struct Loader {
     typedef typename ADDR::P P;
+    typedef ADDR ADDR_T;
+    static constexpr int VEC_W = VEC;
     static_assert(!TR || (!ADDR::KC && !PERM && BK % 4 == 0 && ROWS % 32 == 0), "the transposing form is for row-contiguous operands");
     static constexpr bool KC = ADDR::KC;
     static constexpr bool TRANSPOSED = TR;
@@ -647,6 +649,11 @@ struct Loader {
         }
     }
 
+    // LDS-DMA form (MC_LDS_DMA builds, row-contiguous operands on the vector path): the chunk goes from memory straight to its
+    // place in the stage -- buffer_load_dwordx4 ... lds writes lane l's 16 bytes at (wave-uniform base) + 16 l, which IS the plain
+    // [k][rows] layout for a wave's 64 consecutive chunks, and a lane whose offset is out of the descriptor's range writes zeros
+    // (tools/census/lds_dma_probe.hip) -- so the producers hold no tile registers and issue no ds_write.  wv: this wave's index
+    // among the producers (uniform).  The loads are counted by the caller (dma_count) for its own s_waitcnt vmcnt.
     // k-sums of a k-contiguous operand (weight gradients: the operand is the layer's output gradient, its sum over k the bias
     // gradient): each producer thread adds the four k values of its chunks, in k order, to one partial per chunk slot; a row's
     // BK / 4 partials sit in consecutive lanes and are combined when the K loop is over (sum_rows).  The order depends on BK and on
@@ -798,6 +805,105 @@ template <class ADDR> constexpr bool tr_nat(int rows, int other, int vec) { retu
 template <class ADDR, int ROWS, int OTHER, int BK, int VEC, bool PERM = false>
 using LoaderT = Loader<ADDR, ROWS, BK, VEC, PERM, tr_nat<ADDR>(ROWS, OTHER, VEC)>;
 
+template <class L, bool TAB>
+struct LdsDma {
+__device__ static __forceinline__ void run(float* stage, __amdgpu_buffer_rsrc_t rs, const typename L::P& p, const ConvG& cg, int g, int b, int k0, int kend,
+                                    int x0, int xlim, int tid, int wv, const int2* ktab, const KCol* cols) {
+    typedef typename L::ADDR_T ADDR;
+    constexpr int NCH = L::NCH, CHUNKS = L::CHUNKS;
+    static_assert(!L::KC && !L::TRANSPOSED && L::VEC_W == 4 && CHUNKS % 64 == 0, "LDS-DMA: row-contiguous operands, whole waves of chunks");
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    unsigned off[NCH];
+    if constexpr (has_ktab<ADDR>::value && TAB) {
+        const unsigned limY = (unsigned)ADDR::ktab_limY(cg), limX = (unsigned)ADDR::ktab_limX(cg);
+        typedef int i32x2 __attribute__((ext_vector_type(2)));
+        int2 ent[NCH];
+        i32x2 raw[NCH];
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) {
+            int dk, dx;
+            bool live;
+            L::pos(it, tid, dk, dx, live);
+            // the table is read behind the compiler's back: it takes an ordinary LDS read after an LDS-DMA load for a possible
+            // alias of the load's destination and drains every load in flight first (s_waitcnt vmcnt(0) before each read)
+            typedef __attribute__((address_space(3))) const int2* lds_tab;
+            const unsigned la = (unsigned)(size_t)(lds_tab)(ktab + k0 + dk);
+            asm volatile("ds_read_b64 %0, %1" : "=v"(raw[it]) : "v"(la));
+        }
+        // every entry passes through a wait of its own (the repeats cost a cycle each): a use of the value cannot be scheduled
+        // ahead of the wait it depends on
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[it]));
+            ent[it] = make_int2(raw[it].x, raw[it].y);
+        }
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) {
+            int dk, dx;
+            bool live;
+            L::pos(it, tid, dk, dx, live);
+            const int2 e = ent[it];
+            const int dy = (int)(short)(e.y & 0xFFFF), dxx = e.y >> 16;
+            const KCol& cl = cols[it];
+            const bool ok = ((unsigned)(cl.cy + dy) < limY) & ((unsigned)(cl.cx + dxx) < limX) & (k0 + dk < kend);
+            off[it] = ok ? (unsigned)(cl.base + e.x) * 4u : OOB;
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) {
+            int dk, dx;
+            bool live;
+            L::pos(it, tid, dk, dx, live);
+            const int k = k0 + dk, x = x0 + dx;
+            int o;
+            const bool ok = ADDR::addr(p, cg, g, b, k, x, o) & (k < kend) & (x < xlim);
+            off[it] = ok ? (unsigned)o * 4u : OOB;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NCH; ++it)
+        if (CHUNKS % THREADS == 0 || wv * 64 + it * THREADS < CHUNKS)   // wave-uniform
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(stage + (wv * 64 + it * THREADS) * 4), 16, off[it], 0, 0, 0);
+}
+};
+// loads of wave wv per tile of loader L
+template <class L> __device__ __forceinline__ int lds_dma_count(int wv) { return (L::CHUNKS - wv * 64 + THREADS - 1) / THREADS; }
+
+// LDS stages.  Three with the register-staged producers.  The dense products whose operands are both row-contiguous (the
+// backward-data product of a dense / cccp layer: vector path, 32x32 tiles, one K chunk owner per tile) have LDS-DMA producers
+// instead, which keep their tiles in flight in LDS rather than in registers and so want the stages of the tiles in flight on
+// top of the two being read: MC_LDS_DMA stages (4: measured against 5 and 6, which cost residency and gain nothing).
+// Measured on the NIN shapes (same box, default build against this one): cccp backward-data 4-7 % faster (89.8 -> 85.8,
+// 51.1 -> 48.7, 30.8 -> 28.7 us).  The convolution forward (-DMC_LDS_DMA_CONV, its K table read by hand-written LDS reads) is
+// unchanged at 5x5x192 and 9 % slower at 3x3x192 -- the fourth stage costs it residency, and what its producers cost the
+// consumers is LDS bandwidth, which the DMA path uses just the same -- so it keeps the register-staged producers.
+// -DMC_NO_LDS_DMA: register-staged producers everywhere.
+#ifndef MC_LDS_DMA
+#define MC_LDS_DMA 4
+#endif
+#ifdef MC_NO_LDS_DMA
+template <class A, class B> constexpr int n_stages(int, int, int) { return 3; }
+#else
+template <class A, class B> constexpr int n_stages(int vec, int kq, int mf) {
+#ifdef MC_LDS_DMA_CONV
+    constexpr bool conv = true;
+#else
+    constexpr bool conv = !has_ktab<B>::value;
+#endif
+    return (!A::KC && !B::KC && conv && vec == 4 && kq == 1 && mf == 0) ? MC_LDS_DMA : 3;
+}
+#endif
+// s_waitcnt vmcnt(n) for a run-time (uniform) n; waiting for fewer loads in flight than allowed is always correct
+__device__ __forceinline__ void wait_vm(int n) {
+    switch (n) {
+#define MC_VM_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+        MC_VM_CASE(0) MC_VM_CASE(1) MC_VM_CASE(2) MC_VM_CASE(3) MC_VM_CASE(4) MC_VM_CASE(5) MC_VM_CASE(6) MC_VM_CASE(7) MC_VM_CASE(8)
+        MC_VM_CASE(9) MC_VM_CASE(10) MC_VM_CASE(11) MC_VM_CASE(12) MC_VM_CASE(13) MC_VM_CASE(14) MC_VM_CASE(15)
+#undef MC_VM_CASE
+        default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    }
+}
+
 template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC, int NS, int EPI, int KQ, int MF = 0>
 __global__ void __launch_bounds__(2 * THREADS)
 #ifndef MC_NO_T51_CAP   // the 160-row tile sits 3-17 registers above 128 = two resident workgroups per CU: cap it (a few spills outside the K loop)
@@ -818,6 +924,7 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     // near its end, prefetch the first fragments of stage (t+1) % 3, complete since the previous barrier)
     // while the producers fill stage (t+2) % 3.
     constexpr int STAGE = LA::LDS_FLOATS + LB::LDS_FLOATS;
+    constexpr int NSTG = n_stages<AADDR, BADDR>(VEC, KQ, MF);   // 3, or more with LDS-DMA producers (tile u then lives in stage u % NSTG)
 
     // Column tiles.  A workgroup is a "column worker": worker w = blockIdx.x of gridDim.x takes column tiles
     // w, w + gridDim.x, ... and runs their K loops back to back as ONE pipeline of nTiles * nk steps, so only the
@@ -857,7 +964,7 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     const int2* ktab = nullptr;
     if constexpr (has_ktab<BADDR>::value) {
         if (d.ktabN) {
-            int2* tab = reinterpret_cast<int2*>(smem + 3 * STAGE + BM);
+            int2* tab = reinterpret_cast<int2*>(smem + NSTG * STAGE + BM);
             for (int k = threadIdx.x; k < d.ktabN; k += 2 * THREADS) tab[k] = BADDR::ktab_entry(cg, k < d.Kg ? k : 0);
             ktab = tab;
             lds_done_barrier();
@@ -953,7 +1060,7 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
             if (u < nk) fetch(as[u], u);
         // per-row bias of this tile -> LDS (behind the three stages), so the epilogue does not wait on one global load
         // per output row; visible to the consumers through the first barrier
-        if (tid < BM) smem[3 * STAGE + tid] = (ep.bias && i0 + tid < d.Mg) ? ep.bias[i0 + tid + g * ep.rowG] : 0.f;
+        if (tid < BM) smem[NSTG * STAGE + tid] = (ep.bias && i0 + tid < d.Mg) ? ep.bias[i0 + tid + g * ep.rowG] : 0.f;
         commit(as[0], 0);
         if (NS < nk) fetch(as[0], NS);
         if (1 < nk) {
@@ -1022,7 +1129,61 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
                 produce(persist_, tab_, std::integral_constant<int, 0>{});
             }
         };
+        // LDS-DMA producers (NSTG > 3): tile u is loaded straight into stage u % NSTG.  NSTG - 1 tiles are issued before the first
+        // barrier; during K step t tile t + NSTG - 1 is issued into the stage the consumers left at the previous barrier, and the
+        // barrier that ends step t waits until tile t + 2 has landed (the consumers prefetch its first fragments during step
+        // t + 1): a wave's loads complete in order, so that is "at most (tiles issued after t + 2) x (loads per tile of this
+        // wave) still in flight".  No tile registers, no ds_write, no compiler bookkeeping to keep exact.
+        auto produce_dma = [&](auto persist_, auto tab_) {
+            constexpr bool PERSIST = decltype(persist_)::value;
+            constexpr bool TAB = decltype(tab_)::value;
+            if constexpr (NSTG > 3) {
+                int fk = 0, fj0 = coff + col_block(blockIdx.x) * BN, ft = blockIdx.x, istage = 0;
+                KCol bcols[LB::NCOL];
+                if (TAB) LB::prep_cols(bcols, pb, cg, g, fj0, jlim, tid);
+                const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+                const int lw = lds_dma_count<LA>(wv) + lds_dma_count<LB>(wv);
+                auto issue = [&](auto) {   // (generic: the body is checked only where it is instantiated, on the device side)
+                    float* st = smem + istage * STAGE;
+                    const int k0 = kbeg + fk * d.kStep;
+                    LdsDma<LA, false>::run(st, ra, pa, cg, g, b, k0, kend, i0, ilim, tid, wv, nullptr, nullptr);
+                    LdsDma<LB, TAB>::run(st + LA::LDS_FLOATS, rb, pb, cg, g, b, k0, kend, fj0, jlim, tid, wv, ktab, bcols);
+                    istage = istage == NSTG - 1 ? 0 : istage + 1;
+                    ++fk;
+                    if (PERSIST && fk == nkTile) {
+                        fk = 0;
+                        ft += gridDim.x;
+                        fj0 = coff + col_block(ft) * BN;
+                        if (TAB) LB::prep_cols(bcols, pb, cg, g, fj0, jlim, tid);
+                    }
+                };
+                const int pre = nk < NSTG - 1 ? nk : NSTG - 1;
+                // (the bias column first: an ordinary LDS store after an LDS-DMA load makes the compiler drain the loads in flight)
+                if (tid < BM) smem[NSTG * STAGE + tid] = (ep.bias && i0 + tid < d.Mg) ? ep.bias[i0 + tid + g * ep.rowG] : 0.f;
+                for (int u = 0; u < pre; ++u) issue(0);
+                wait_vm((pre > 2 ? pre - 2 : 0) * lw);
+                lds_done_barrier();   // tiles 0 and 1 visible
+                for (int t = 0; t < nk; ++t) {
+                    if (t + NSTG - 1 < nk) issue(0);
+                    const int last = t + NSTG - 1 < nk ? t + NSTG - 1 : nk - 1;   // newest tile issued
+                    wait_vm((last > t + 2 ? last - (t + 2) : 0) * lw);
+                    lds_done_barrier();   // end of K step t
+                }
+            }
+        };
         const bool onePerTile = (int)gridDim.x == d.colTiles;
+        if constexpr (NSTG > 3) {
+            if constexpr (has_ktab<BADDR>::value) {
+                if (ktab) {
+                    if (onePerTile) produce_dma(std::false_type{}, std::true_type{});
+                    else produce_dma(std::true_type{}, std::true_type{});
+                    return;
+                }
+            }
+            if (onePerTile) produce_dma(std::false_type{}, std::false_type{});
+            else produce_dma(std::true_type{}, std::false_type{});
+            return;
+        } else {
         if constexpr (has_ktab<BADDR>::value) {
             if (ktab) {
                 if (onePerTile) produce_roles(std::false_type{}, std::true_type{});
@@ -1033,6 +1194,7 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         if (onePerTile) produce_roles(std::false_type{}, std::false_type{});
         else produce_roles(std::true_type{}, std::false_type{});
         return;
+        }
     }
 
     if constexpr (MF == 1) {
@@ -1075,7 +1237,7 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
 #pragma unroll
                 for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int t = 0; t < nkTile; ++t) {
-                const int nstage = stage == 2 ? 0 : stage + 1;
+                const int nstage = stage == NSTG - 1 ? 0 : stage + 1;
                 const float* cA = smem + stage * STAGE;
                 const float* cB = cA + LA::LDS_FLOATS;
                 const float* nA = smem + nstage * STAGE;   // on the last K step this stage holds stale data: read, never used
@@ -1121,7 +1283,7 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
                 __builtin_amdgcn_sched_barrier(0);   // a block row at a time
                 const int rl0 = (wm * MT + a) * 16 + 4 * lqq;
                 const int iB = i0 + rl0;
-                const float4 bq = *reinterpret_cast<const float4*>(&smem[3 * STAGE + rl0]);
+                const float4 bq = *reinterpret_cast<const float4*>(&smem[NSTG * STAGE + rl0]);
                 const float bia[4] = {bq.x, bq.y, bq.z, bq.w};
                 const unsigned rowB = (unsigned)(iB + g * ep.rowG) * ldcB;
 #pragma unroll
@@ -1295,7 +1457,7 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
                         const unsigned off = ok ? (unsigned)(row * ep.ldc + j + g * ep.colG) * 4u : OOB;
                         float v = ep.alpha * acc[a][b][r];
                         if (ep.beta != 0.f) v += ep.beta * __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rc, off, 0, 0));
-                        if (ep.bias) v += smem[3 * STAGE + rl];
+                        if (ep.bias) v += smem[NSTG * STAGE + rl];
                         if (ep.act == MC_NEURON_RELU) v = v < 0.f ? 0.f : v;
                         if (ep.mask) {
                             const unsigned moff = ok ? (unsigned)(row * ep.ldmask + j + g * ep.colG) * 4u : OOB;
@@ -1319,12 +1481,12 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
                 unsigned pb[NT];   // (output > 0) of this lane's 16 elements of block (a, b)
 #pragma unroll
                 for (int b = 0; b < NT; ++b) pb[b] = 0;
-                float4 bq = *reinterpret_cast<const float4*>(&smem[3 * STAGE + rl0]);
+                float4 bq = *reinterpret_cast<const float4*>(&smem[NSTG * STAGE + rl0]);
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
                     __builtin_amdgcn_sched_barrier(0);   // one group at a time: hoisted, the loads and offsets of a whole tile are 40+ live registers
                     float4 bn = bq;
-                    if (q4 < 3) bn = *reinterpret_cast<const float4*>(&smem[3 * STAGE + rl0 + 8 * (q4 + 1)]);
+                    if (q4 < 3) bn = *reinterpret_cast<const float4*>(&smem[NSTG * STAGE + rl0 + 8 * (q4 + 1)]);
                     const float bia[4] = {bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
                     for (int b = 0; b < NT; ++b) {
@@ -1386,7 +1548,7 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         for (int b = 0; b < NT; ++b) cs[b] = 0.f;
     }
     for (int t = 0; t < nkTile; ++t) {
-        const int nstage = stage == 2 ? 0 : stage + 1;
+        const int nstage = stage == NSTG - 1 ? 0 : stage + 1;
         STAMP(c0);
         const float* cA = smem + stage * STAGE;
         const float* cB = cA + LA::LDS_FLOATS;
@@ -1429,7 +1591,7 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
         // are free: the kq = 1 waves park their accumulators there, lane-major (conflict-free), the kq = 0 waves add them.
         // (A barrier counts only the waves that have not ended.)
         float* red = smem + (size_t)w2 * (MT * NT * 16 * 64);
-        static_assert((size_t)WM * WN * MT * NT * 16 * 64 <= (size_t)3 * STAGE, "accumulator hand-over must fit the stages");
+        static_assert((size_t)WM * WN * MT * NT * 16 * 64 <= (size_t)NSTG * STAGE, "accumulator hand-over must fit the stages");
         if (kq == 1) {
 #pragma unroll
             for (int a = 0; a < MT; ++a)
@@ -1498,7 +1660,7 @@ int launch_cfg(const typename AADDR::P& pa, const typename BADDR::P& pb, const C
     constexpr int BM = (MF ? 16 : 32) * MT * WM, BN = (MF ? 16 : 32) * NT * WN;
     typedef LoaderT<AADDR, BM, BN, BK, VEC> LA;
     typedef LoaderT<BADDR, BN, BM, BK, VEC> LB;
-    constexpr size_t ldsTile = (3 * (LA::LDS_FLOATS + LB::LDS_FLOATS) + BM) * sizeof(float);   // three stages + the tile's bias column
+    constexpr size_t ldsTile = (n_stages<AADDR, BADDR>(VEC, KQ, MF) * (LA::LDS_FLOATS + LB::LDS_FLOATS) + BM) * sizeof(float);   // the stages + the tile's bias column
     static_assert(ldsTile <= 160 * 1024, "LDS budget");
     auto kern = mc_igemm<AADDR, BADDR, MT, NT, WM, WN, BK, VEC, NS, EPI, KQ, MF>;
     Dims d = d0;
@@ -1576,7 +1738,7 @@ inline bool is_mf_tile(int t) { return t >= M56 && t <= M33; }
 // only the tiles that still fit 160 KB; launch_tile maps the others to the nearest one that does.
 template <class AADDR, class BADDR, int MT, int NT, int WM, int WN, int BK, int VEC, int UNIT = 32>
 constexpr bool tile_fits() {
-    return (3 * (size_t)(LoaderT<AADDR, UNIT * MT * WM, UNIT * NT * WN, BK, VEC>::LDS_FLOATS + LoaderT<BADDR, UNIT * NT * WN, UNIT * MT * WM, BK, VEC>::LDS_FLOATS) + UNIT * MT * WM) * sizeof(float) <= 160 * 1024;
+    return (n_stages<AADDR, BADDR>(VEC, 1, UNIT == 16) * (size_t)(LoaderT<AADDR, UNIT * MT * WM, UNIT * NT * WN, BK, VEC>::LDS_FLOATS + LoaderT<BADDR, UNIT * NT * WN, UNIT * MT * WM, BK, VEC>::LDS_FLOATS) + UNIT * MT * WM) * sizeof(float) <= 160 * 1024;
 }
 // the 16x16x4 tiles exist for these products only
 template <class AADDR, class BADDR, int BK, int EPI>
