@@ -19,8 +19,8 @@ FAMILY = [   # (profile-key regex, kernel-name regex)
     (r"/fwd:mc_conv_filter_acts", r"mc_igemm<MatNatAddr, PatchNat"),
     (r"/bwd:mc_conv_img_acts", r"mc_igemm<MatKcAddr, HidNat"),
     (r"/wgrad:mc_conv_weight_grad", r"mc_igemm<PatchKc\w*, MatKc"),
-    (r"/fwd:mc_gemm", r"mc_igemm<MatNatAddr, MatNatAddr"),
-    (r"/bwd:mc_gemm", r"mc_igemm<MatKcAddr, MatNatAddr"),
+    (r"/fwd:mc_gemm", r"mc_igemm<MatKcAddr, MatNatAddr"),    # W (out x in, k-contiguous) . x
+    (r"/bwd:mc_gemm", r"mc_igemm<MatNatAddr, MatNatAddr"),   # W^T . grad: both operands row-contiguous
     (r"/wgrad:mc_gemm", r"mc_igemm<MatKc\w*, MatKc"),
     (r":mc_conv_local_pool", r"k_pool"),
     (r":mc_conv_local_max_undo", r"k_max_undo"),
