@@ -422,7 +422,8 @@ template <class ADDR, int ROWS, int BK, int VEC, bool PERM = false, bool TR = fa
 struct Loader {
     typedef typename ADDR::P P;
     typedef ADDR ADDR_T;
-    static constexpr int VEC_W = VEC;
+    static constexpr int VEC_W = VEC, ROWS_N = ROWS, BK_N = BK;
+    static constexpr bool PERM_F = PERM;
     static_assert(!TR || (!ADDR::KC && !PERM && BK % 4 == 0 && ROWS % 32 == 0), "the transposing form is for row-contiguous operands");
     static constexpr bool KC = ADDR::KC;
     static constexpr bool TRANSPOSED = TR;
@@ -811,8 +812,31 @@ __device__ static __forceinline__ void run(float* stage, __amdgpu_buffer_rsrc_t 
                                     int x0, int xlim, int tid, int wv, const int2* ktab, const KCol* cols) {
     typedef typename L::ADDR_T ADDR;
     constexpr int NCH = L::NCH, CHUNKS = L::CHUNKS;
-    static_assert(!L::KC && !L::TRANSPOSED && L::VEC_W == 4 && CHUNKS % 64 == 0, "LDS-DMA: row-contiguous operands, whole waves of chunks");
     typedef __attribute__((address_space(3))) void* lds_ptr;
+    if constexpr (L::KC) {
+        // k-contiguous operand (the small one of a dense forward product: the weights): its stage image [k-quad][row] x 16 bytes is
+        // lane-linear in the ROW, so a wave load takes one k-quad of 64 consecutive rows -- 64 separate 16-byte pieces of memory, a
+        // pattern only a small, cache-resident operand should be given.  Lanes past the tile's last row are switched off (they
+        // would land in the next k-quad's rows); rows past the matrix edge load zeros like every out-of-range lane.
+        static_assert(!L::PERM_F && !L::TRANSPOSED && L::VEC_W == 4, "LDS-DMA: plain k-quad layout");
+        constexpr int WPR = (L::ROWS_N + 63) / 64, NW = (L::BK_N / 4) * WPR;   // wave loads per k-quad / per tile
+        const int lane = tid & 63;
+#pragma unroll
+        for (int it = 0; it < (NW + 3) / 4; ++it) {
+            const int w = wv + 4 * it;
+            if (w < NW) {   // wave-uniform
+                const int kq = w / WPR, rb = (w % WPR) * 64, row = rb + lane;
+                const int k = k0 + 4 * kq, x = x0 + row;
+                int o;
+                const bool ok = ADDR::addr(p, cg, g, b, k, x, o) & (k < kend) & (x < xlim);
+                const unsigned off = ok ? (unsigned)o * 4u : OOB;
+                if (L::ROWS_N % 64 == 0 || row < L::ROWS_N)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(stage + (kq * L::ROWSP + rb) * 4), 16, off, 0, 0, 0);
+            }
+        }
+        return;
+    }
+    static_assert(L::KC || (!L::TRANSPOSED && L::VEC_W == 4 && CHUNKS % 64 == 0), "LDS-DMA: row-contiguous operands, whole waves of chunks");
     unsigned off[NCH];
     if constexpr (has_ktab<ADDR>::value && TAB) {
         const unsigned limY = (unsigned)ADDR::ktab_limY(cg), limX = (unsigned)ADDR::ktab_limX(cg);
@@ -867,7 +891,10 @@ __device__ static __forceinline__ void run(float* stage, __amdgpu_buffer_rsrc_t 
 }
 };
 // loads of wave wv per tile of loader L
-template <class L> __device__ __forceinline__ int lds_dma_count(int wv) { return (L::CHUNKS - wv * 64 + THREADS - 1) / THREADS; }
+template <class L> __device__ __forceinline__ int lds_dma_count(int wv) {
+    if (L::KC) return ((L::BK_N / 4) * ((L::ROWS_N + 63) / 64) - wv + 3) / 4;
+    return (L::CHUNKS - wv * 64 + THREADS - 1) / THREADS;
+}
 
 // LDS stages.  Three with the register-staged producers.  The dense products whose operands are both row-contiguous (the
 // backward-data product of a dense / cccp layer: vector path, 32x32 tiles, one K chunk owner per tile) have LDS-DMA producers
@@ -890,7 +917,13 @@ template <class A, class B> constexpr int n_stages(int vec, int kq, int mf) {
 #else
     constexpr bool conv = !has_ktab<B>::value;
 #endif
-    return (!A::KC && !B::KC && conv && vec == 4 && kq == 1 && mf == 0) ? MC_LDS_DMA : 3;
+    // (a k-contiguous A operand only as the plain weight matrix of a dense forward product: see LdsDma)
+#ifdef MC_NO_LDS_DMA_KC
+    constexpr bool aok = !A::KC;
+#else
+    constexpr bool aok = !A::KC || std::is_same<A, MatKcAddr>::value;
+#endif
+    return (aok && !B::KC && conv && vec == 4 && kq == 1 && mf == 0) ? MC_LDS_DMA : 3;
 }
 #endif
 // s_waitcnt vmcnt(n) for a run-time (uniform) n; waiting for fewer loads in flight than allowed is always correct
