@@ -1364,7 +1364,10 @@ mc_igemm(typename AADDR::P pa, typename BADDR::P pb, ConvG cg, Dims d, Epi ep) {
     // MFMA k-step (2 k values: lane half h supplies k = kof(s) + h-dependent offset).  The reads of slab
     // s+PF are issued before the MFMAs of slab s; the last PF slabs of a K step prefetch the first PF
     // slabs of the NEXT stage, so the matrix pipe does not drain at the barrier.
-    constexpr int SLABS = BK / 2 / KQ, PF = 2;   // slabs of a K step this wave multiplies (its half when KQ == 2)
+#ifndef MC_PF
+#define MC_PF 2   // fragment prefetch distance in slabs
+#endif
+    constexpr int SLABS = BK / 2 / KQ, PF = MC_PF;   // slabs of a K step this wave multiplies (its half when KQ == 2)
     static_assert(SLABS >= 4 + PF && SLABS % 4 == 0, "prefetch into consumed fragment registers");
     float af[SLABS][MT], bf[SLABS][NT];
 #ifdef MC_ABL_NOLDSREAD   // timing-only ablation: the consumers read no fragments (what do their LDS reads cost the MFMA stream?)
