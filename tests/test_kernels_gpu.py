@@ -164,6 +164,9 @@ def test_local_triplet(N, C, H, fs, F, pad, stride, groups):
 GEMM_CASES = [  # m, n, k
     (160, 1024 * 16, 192), (96, 4096, 160), (10, 8192, 192), (64, 128, 1024), (10, 128, 64),
     (192, 192, 4096), (37, 53, 29), (2048, 128, 2560),
+    # vector path (every extent a multiple of 4) with ragged tiles and a K tail inside the last 16-k step: the LDS-DMA producers'
+    # out-of-range lanes (rows / columns past the edge, k past the end) must land as zeros, partial waves of weight rows stay off
+    (200, 640, 100), (72, 336, 52), (132, 260, 36),
 ]
 
 
