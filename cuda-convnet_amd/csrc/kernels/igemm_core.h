@@ -650,11 +650,6 @@ struct Loader {
         }
     }
 
-    // LDS-DMA form (MC_LDS_DMA builds, row-contiguous operands on the vector path): the chunk goes from memory straight to its
-    // place in the stage -- buffer_load_dwordx4 ... lds writes lane l's 16 bytes at (wave-uniform base) + 16 l, which IS the plain
-    // [k][rows] layout for a wave's 64 consecutive chunks, and a lane whose offset is out of the descriptor's range writes zeros
-    // (tools/census/lds_dma_probe.hip) -- so the producers hold no tile registers and issue no ds_write.  wv: this wave's index
-    // among the producers (uniform).  The loads are counted by the caller (dma_count) for its own s_waitcnt vmcnt.
     // k-sums of a k-contiguous operand (weight gradients: the operand is the layer's output gradient, its sum over k the bias
     // gradient): each producer thread adds the four k values of its chunks, in k order, to one partial per chunk slot; a row's
     // BK / 4 partials sit in consecutive lanes and are combined when the K loop is over (sum_rows).  The order depends on BK and on
@@ -806,6 +801,13 @@ template <class ADDR> constexpr bool tr_nat(int rows, int other, int vec) { retu
 template <class ADDR, int ROWS, int OTHER, int BK, int VEC, bool PERM = false>
 using LoaderT = Loader<ADDR, ROWS, BK, VEC, PERM, tr_nat<ADDR>(ROWS, OTHER, VEC)>;
 
+// LDS-DMA loader of operand L (the products n_stages() names; vector path): a chunk goes from memory straight to its place in
+// the stage -- buffer_load_dwordx4 ... lds writes lane l's 16 bytes at (wave-uniform base, in M0) + 16 l, which IS the plain
+// [k][rows] layout for a wave's 64 consecutive chunks, and a lane whose offset is out of the descriptor's range writes zeros
+// (tools/census/lds_dma_probe.hip) -- so the producers hold no tile registers and issue no ds_write.  wv: this wave's index among
+// the producers (uniform).  The caller counts the loads (lds_dma_count) for its own s_waitcnt vmcnt.  (A struct with a static
+// member rather than a member template of Loader: called from a second kernel instantiation, that one failed overload
+// resolution on the host pass with no reason given.)
 template <class L, bool TAB>
 struct LdsDma {
 __device__ static __forceinline__ void run(float* stage, __amdgpu_buffer_rsrc_t rs, const typename L::P& p, const ConvG& cg, int g, int b, int k0, int kend,
